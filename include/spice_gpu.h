@@ -1,0 +1,302 @@
+/*
+ * libspicegpu -- C ABI of the MI355X image-compression path of the SPICE
+ * display server.
+ *
+ * Section 1 re-exports, with the reference's own names, argument meaning and
+ * error behaviour, the encoder-library entry points that red_worker.c calls,
+ * so that libspice-server can link this library instead of compiling
+ * glz_encoder.c / glz_encoder_dictionary.c / mjpeg_encoder.c / jpeg_encoder.c.
+ * Host pointers in, host buffers out, synchronous.
+ *
+ * Section 2 is the device-resident batch interface the throughput figures are
+ * measured on: pixels already in HBM, compressed bytes left in HBM, many
+ * sessions / frames per call.
+ *
+ * No type from HIP or any other runtime appears here: device memory is a
+ * plain pointer, a stream is a void *.
+ */
+#ifndef SPICE_GPU_H
+#define SPICE_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ======================================================================
+ * Section 0 -- library state
+ * ====================================================================== */
+
+/* Selects the GPU this process encodes on and creates the library's stream.
+ * Returns 0, or -1 (see spice_gpu_last_error) e.g. when no GPU is visible.
+ * Every other entry point fails the same way when no device is usable: there
+ * is no CPU fallback. */
+int spice_gpu_init(int device);
+void spice_gpu_shutdown(void);
+const char *spice_gpu_last_error(void);
+/* The library's own HIP stream (a hipStream_t), for callers that want to
+ * bracket launches with their own events. */
+void *spice_gpu_stream(void);
+
+/* ======================================================================
+ * Section 1a -- GLZ, drop-in for server/glz_encoder.h:28-52,
+ * server/glz_encoder_dictionary.h:30-67, server/glz_encoder_config.h:24-44
+ * ====================================================================== */
+
+/* LzImageType: order fixed by server/red_common.h:39-51 and
+ * client/glz_decoder.cpp:212-236 (the enum itself lives in spice-common). */
+typedef enum {
+    LZ_IMAGE_TYPE_INVALID,
+    LZ_IMAGE_TYPE_PLT1_LE,
+    LZ_IMAGE_TYPE_PLT1_BE,
+    LZ_IMAGE_TYPE_PLT4_LE,
+    LZ_IMAGE_TYPE_PLT4_BE,
+    LZ_IMAGE_TYPE_PLT8,
+    LZ_IMAGE_TYPE_RGB16,
+    LZ_IMAGE_TYPE_RGB24,
+    LZ_IMAGE_TYPE_RGB32,
+    LZ_IMAGE_TYPE_RGBA,
+    LZ_IMAGE_TYPE_XXXA,
+    LZ_IMAGE_TYPE_A8
+} LzImageType;
+
+typedef void GlzEncoderContext;
+typedef void GlzEncDictContext;
+typedef void GlzEncDictImageContext;
+typedef void GlzUsrImageContext;
+typedef struct GlzEncoderUsrContext GlzEncoderUsrContext;
+
+/* server/glz_encoder_config.h:27-44 -- same member order, same meaning */
+struct GlzEncoderUsrContext {
+    void (*error)(GlzEncoderUsrContext *usr, const char *fmt, ...);
+    void (*warn)(GlzEncoderUsrContext *usr, const char *fmt, ...);
+    void (*info)(GlzEncoderUsrContext *usr, const char *fmt, ...);
+    void *(*malloc)(GlzEncoderUsrContext *usr, int size);
+    void (*free)(GlzEncoderUsrContext *usr, void *ptr);
+    /* next chunk of image rows; returns the number of rows */
+    int (*more_lines)(GlzEncoderUsrContext *usr, uint8_t **lines);
+    /* next chunk of output space; returns its size in bytes */
+    int (*more_space)(GlzEncoderUsrContext *usr, uint8_t **io_ptr);
+    /* an image left the window because of the size limit */
+    void (*free_image)(GlzEncoderUsrContext *usr, GlzUsrImageContext *image);
+};
+
+/* server/glz_encoder_dictionary.h:34-38 */
+typedef struct GlzEncDictRestoreData {
+    uint32_t size;
+    uint32_t max_encoders;
+    uint64_t last_image_id;
+} GlzEncDictRestoreData;
+
+/* server/glz_encoder_dictionary.h:43-44.  size: window capacity in pixels
+ * (at most 2^25).  The window's pixel copies and the 2^20-entry hash table
+ * live in HBM. */
+GlzEncDictContext *glz_enc_dictionary_create(uint32_t size, uint32_t max_encoders,
+                                             GlzEncoderUsrContext *usr);
+/* server/glz_encoder_dictionary.h:46 */
+void glz_enc_dictionary_destroy(GlzEncDictContext *opaque_dict, GlzEncoderUsrContext *usr);
+/* server/glz_encoder_dictionary.h:49 */
+uint32_t glz_enc_dictionary_get_size(GlzEncDictContext *opaque_dict);
+/* server/glz_encoder_dictionary.h:53-55 */
+void glz_enc_dictionary_get_restore_data(GlzEncDictContext *opaque_dict,
+                                         GlzEncDictRestoreData *out_data,
+                                         GlzEncoderUsrContext *usr);
+/* server/glz_encoder_dictionary.h:58-59 */
+GlzEncDictContext *glz_enc_dictionary_restore(GlzEncDictRestoreData *restore_data,
+                                              GlzEncoderUsrContext *usr);
+/* server/glz_encoder_dictionary.h:62 */
+void glz_enc_dictionary_reset(GlzEncDictContext *opaque_dict, GlzEncoderUsrContext *usr);
+/* server/glz_encoder_dictionary.h:66-67 -- logical removal, no callback */
+void glz_enc_dictionary_remove_image(GlzEncDictContext *opaque_dict,
+                                     GlzEncDictImageContext *image, GlzEncoderUsrContext *usr);
+
+/* server/glz_encoder.h:30-33 */
+GlzEncoderContext *glz_encoder_create(uint8_t id, GlzEncDictContext *dictionary,
+                                      GlzEncoderUsrContext *usr);
+void glz_encoder_destroy(GlzEncoderContext *opaque_encoder);
+
+/* server/glz_encoder.h:49-52.  Returns the compressed size in bytes.  Rows
+ * are pulled through usr->more_lines when lines == NULL / num_lines == 0, one
+ * window segment per chunk; output goes to io_ptr and then to the buffers
+ * usr->more_space hands out.  Unlike the reference the window keeps its own
+ * copy of the pixels (in HBM), so the caller's rows may be released as soon
+ * as the call returns; free_image still fires on the reference's schedule. */
+int glz_encode(GlzEncoderContext *opaque_encoder, LzImageType type, int width, int height,
+               int top_down, uint8_t *lines, unsigned int num_lines, int stride,
+               uint8_t *io_ptr, unsigned int num_io_bytes, GlzUsrImageContext *usr_context,
+               GlzEncDictImageContext **o_enc_dict_context);
+
+/* ======================================================================
+ * Section 1b -- MJPEG, drop-in for server/mjpeg_encoder.h:24-112
+ * ====================================================================== */
+
+enum {
+    MJPEG_ENCODER_FRAME_UNSUPPORTED = -1,
+    MJPEG_ENCODER_FRAME_DROP,
+    MJPEG_ENCODER_FRAME_ENCODE_START
+};
+
+/* SPICE_BITMAP_FMT_* values used by this path (server/red_worker.c:511-512) */
+enum {
+    SPICE_GPU_BITMAP_FMT_16BIT = 6,
+    SPICE_GPU_BITMAP_FMT_24BIT = 7,
+    SPICE_GPU_BITMAP_FMT_32BIT = 8,
+    SPICE_GPU_BITMAP_FMT_RGBA = 9
+};
+
+typedef struct MJpegEncoder MJpegEncoder;
+
+/* server/mjpeg_encoder.h:40-44 */
+typedef struct MJpegEncoderRateControlCbs {
+    uint32_t (*get_roundtrip_ms)(void *opaque);
+    uint32_t (*get_source_fps)(void *opaque);
+    void (*update_client_playback_delay)(void *opaque, uint32_t delay_ms);
+} MJpegEncoderRateControlCbs;
+
+/* server/mjpeg_encoder.h:46-50 */
+typedef struct MJpegEncoderStats {
+    uint64_t starting_bit_rate;
+    uint64_t cur_bit_rate;
+    double avg_quality;
+} MJpegEncoderStats;
+
+/* server/mjpeg_encoder.h:52-54.  Only bit_rate_control == 0 is accepted in
+ * this build (static quality 70, server/mjpeg_encoder.c:33,213); rate control
+ * is host policy layered on top of the codec and is not part of this path.
+ * Returns NULL, with spice_gpu_last_error set, when asked for it. */
+MJpegEncoder *mjpeg_encoder_new(int bit_rate_control, uint64_t starting_bit_rate,
+                                MJpegEncoderRateControlCbs *cbs, void *opaque);
+void mjpeg_encoder_destroy(MJpegEncoder *encoder);
+/* server/mjpeg_encoder.h:56 */
+uint8_t mjpeg_encoder_get_bytes_per_pixel(MJpegEncoder *encoder);
+/* server/mjpeg_encoder.h:69-72.  format is a SpiceBitmapFmt.  *dest must be
+ * NULL or malloc()ed; it may be replaced by a larger malloc()ed buffer. */
+int mjpeg_encoder_start_frame(MJpegEncoder *encoder, int format, int width, int height,
+                              uint8_t **dest, size_t *dest_len, uint32_t frame_mm_time);
+/* server/mjpeg_encoder.h:73-74.  Returns rows accepted (1), 0 on failure. */
+int mjpeg_encoder_encode_scanline(MJpegEncoder *encoder, uint8_t *src_pixels, size_t image_width);
+/* server/mjpeg_encoder.h:75.  Runs the frame on the GPU; returns the JFIF size. */
+size_t mjpeg_encoder_end_frame(MJpegEncoder *encoder);
+/* server/mjpeg_encoder.h:111-112 */
+uint64_t mjpeg_encoder_get_bit_rate(MJpegEncoder *encoder);
+void mjpeg_encoder_get_stats(MJpegEncoder *encoder, MJpegEncoderStats *stats);
+
+/* ======================================================================
+ * Section 1c -- still JPEG, drop-in for server/jpeg_encoder.h:35-60
+ * ====================================================================== */
+
+typedef enum {
+    JPEG_IMAGE_TYPE_INVALID,
+    JPEG_IMAGE_TYPE_RGB16,
+    JPEG_IMAGE_TYPE_RGB24,
+    JPEG_IMAGE_TYPE_BGR24,
+    JPEG_IMAGE_TYPE_BGRX32
+} JpegEncoderImageType;
+
+typedef void *JpegEncoderContext;
+typedef struct JpegEncoderUsrContext JpegEncoderUsrContext;
+
+/* server/jpeg_encoder.h:48-51 */
+struct JpegEncoderUsrContext {
+    int (*more_space)(JpegEncoderUsrContext *usr, uint8_t **io_ptr);
+    int (*more_lines)(JpegEncoderUsrContext *usr, uint8_t **lines);
+};
+
+/* server/jpeg_encoder.h:53-54 */
+JpegEncoderContext *jpeg_encoder_create(JpegEncoderUsrContext *usr);
+void jpeg_encoder_destroy(JpegEncoderContext *encoder);
+/* server/jpeg_encoder.h:58-60.  ISLOW DCT, 4:2:0, standard tables; rows top
+ * to bottom, further rows through usr->more_lines, output through io_ptr and
+ * then usr->more_space.  Returns the JFIF size, 0 on failure. */
+int jpeg_encode(JpegEncoderContext *jpeg, int quality, JpegEncoderImageType type, int width,
+                int height, uint8_t *lines, unsigned int num_lines, int stride,
+                uint8_t *io_ptr, unsigned int num_io_bytes);
+
+/* ======================================================================
+ * Section 2 -- device-resident batch interface (no counterpart in the
+ * reference, which encodes one image per call on the worker thread;
+ * these are what server/red_worker.c:6003-6102 and :8341-8377 become when
+ * many display sessions share one GPU)
+ * ====================================================================== */
+
+/* One image for one GLZ encoder.  The image's rows are nchunks runs of whole
+ * rows in device memory; each run becomes one window segment, exactly like a
+ * SpiceChunk on the host path (server/red_worker.c:5700-5728). */
+typedef struct SpiceGpuGlzJob {
+    GlzEncoderContext *encoder;
+    LzImageType type;
+    int width, height, top_down, stride;
+    int nchunks;
+    const void *const *chunk_ptrs;   /* host array of device pointers */
+    const uint32_t *chunk_rows;      /* host array */
+    void *out;                       /* device buffer for the compressed stream */
+    uint32_t out_capacity;
+    GlzUsrImageContext *usr_context;
+    /* results */
+    int32_t out_size;                /* bytes written, or < 0 on error */
+    GlzEncDictImageContext *dict_image;
+} SpiceGpuGlzJob;
+
+/* Bytes the output buffer of a job must hold in the worst case. */
+size_t spice_gpu_glz_out_bound(LzImageType type, int width, int height);
+
+/* Encodes njobs images, at most one per dictionary, in one pass: a copy of
+ * the rows into each dictionary's HBM window, then one parse launch with one
+ * wavefront per job.  Jobs of different dictionaries run concurrently; the
+ * call returns when all results are back.  Returns 0, or -1 with
+ * spice_gpu_last_error set (job fields say which job failed). */
+int spice_gpu_glz_encode_batch(SpiceGpuGlzJob *jobs, int njobs);
+
+/* As above but split in two so that callers can time the device work alone
+ * with events on spice_gpu_stream(): submit enqueues everything, finish waits
+ * and completes the host bookkeeping (post-encode window maintenance). */
+int spice_gpu_glz_submit(SpiceGpuGlzJob *jobs, int njobs);
+int spice_gpu_glz_finish(SpiceGpuGlzJob *jobs, int njobs);
+
+enum { SPICE_GPU_DCT_ISLOW = 0, SPICE_GPU_DCT_IFAST = 1 };
+
+/* One frame / still image for the JPEG kernels. */
+typedef struct SpiceGpuJpegJob {
+    const void *pixels;   /* device pointer to the first (top) row */
+    int format;           /* SPICE_GPU_BITMAP_FMT_* */
+    int width, height;
+    long stride;          /* bytes between rows; negative walks bottom-up */
+    int quality;          /* 1..100, libjpeg scaling */
+    int dct;              /* SPICE_GPU_DCT_* */
+    void *out;            /* device buffer for the JFIF file */
+    uint32_t out_capacity;
+    int32_t out_size;     /* result: bytes written, or < 0 */
+} SpiceGpuJpegJob;
+
+size_t spice_gpu_jpeg_out_bound(int width, int height);
+int spice_gpu_jpeg_encode_batch(SpiceGpuJpegJob *jobs, int njobs);
+int spice_gpu_jpeg_submit(SpiceGpuJpegJob *jobs, int njobs);
+int spice_gpu_jpeg_finish(SpiceGpuJpegJob *jobs, int njobs);
+
+/* Plain device-memory helpers so that hosts without a HIP binding (the C
+ * server, ctypes tests) can stage inputs and fetch results. */
+void *spice_gpu_malloc(size_t bytes);
+void spice_gpu_free(void *dev_ptr);
+int spice_gpu_upload(void *dev_dst, const void *host_src, size_t bytes);
+int spice_gpu_download(void *host_dst, const void *dev_src, size_t bytes);
+
+/* Per-codec counters in the shape of stat_info_t / print_compress_stats
+ * (server/red_worker.c:183-193, 1142-1215). */
+typedef struct SpiceGpuCodecStats {
+    uint64_t count;
+    uint64_t orig_bytes;
+    uint64_t comp_bytes;
+    uint64_t total_ns;
+    uint64_t min_ns;
+    uint64_t max_ns;
+} SpiceGpuCodecStats;
+enum { SPICE_GPU_STAT_GLZ = 0, SPICE_GPU_STAT_MJPEG = 1, SPICE_GPU_STAT_JPEG = 2, SPICE_GPU_STAT_COUNT = 3 };
+void spice_gpu_get_stats(int codec, SpiceGpuCodecStats *out);
+void spice_gpu_reset_stats(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,465 @@
+"""ctypes binding of libspicegpu's C ABI (include/spice_gpu.h).
+
+The classes here mirror the reference's encoder-library interface for the
+image-compression path -- same entry points, argument meaning and callback
+contract as server/glz_encoder.h, server/glz_encoder_dictionary.h,
+server/mjpeg_encoder.h and server/jpeg_encoder.h -- so that host code (and the
+parity tests) drive the GPU path the way red_worker.c drives the CPU encoders:
+rows are pulled through ``more_lines``, output is pushed into 64 KiB buffers
+handed out by ``more_space`` (RedCompressBuf, server/red_worker.c:130,504-509).
+"""
+import ctypes as C
+
+import numpy as np
+
+LZ_IMAGE_TYPE_RGB16, LZ_IMAGE_TYPE_RGB24, LZ_IMAGE_TYPE_RGB32, LZ_IMAGE_TYPE_RGBA = 6, 7, 8, 9
+LZ_BPP = {6: 2, 7: 3, 8: 4, 9: 4}
+BITMAP_FMT_16BIT, BITMAP_FMT_24BIT, BITMAP_FMT_32BIT, BITMAP_FMT_RGBA = 6, 7, 8, 9
+BITMAP_BPP = {6: 2, 7: 3, 8: 4, 9: 4}
+DCT_ISLOW, DCT_IFAST = 0, 1
+JPEG_IMAGE_TYPE_RGB16, JPEG_IMAGE_TYPE_RGB24, JPEG_IMAGE_TYPE_BGR24, JPEG_IMAGE_TYPE_BGRX32 = 1, 2, 3, 4
+MJPEG_ENCODER_FRAME_UNSUPPORTED, MJPEG_ENCODER_FRAME_DROP, MJPEG_ENCODER_FRAME_ENCODE_START = -1, 0, 1
+RED_COMPRESS_BUF_SIZE = 64 * 1024  # server/red_worker.c:130
+
+_MSG_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p, C.c_char_p)
+_MALLOC_CB = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int)
+_FREE_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
+_LINES_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_void_p))
+_SPACE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_void_p))
+_FREE_IMAGE_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
+
+
+class GlzEncoderUsrContext(C.Structure):
+    _fields_ = [("error", _MSG_CB), ("warn", _MSG_CB), ("info", _MSG_CB), ("malloc", _MALLOC_CB),
+                ("free", _FREE_CB), ("more_lines", _LINES_CB), ("more_space", _SPACE_CB),
+                ("free_image", _FREE_IMAGE_CB)]
+
+
+class GlzEncDictRestoreData(C.Structure):
+    _fields_ = [("size", C.c_uint32), ("max_encoders", C.c_uint32), ("last_image_id", C.c_uint64)]
+
+
+class JpegEncoderUsrContext(C.Structure):
+    _fields_ = [("more_space", _SPACE_CB), ("more_lines", _LINES_CB)]
+
+
+class SpiceGpuGlzJob(C.Structure):
+    _fields_ = [("encoder", C.c_void_p), ("type", C.c_int), ("width", C.c_int), ("height", C.c_int),
+                ("top_down", C.c_int), ("stride", C.c_int), ("nchunks", C.c_int),
+                ("chunk_ptrs", C.POINTER(C.c_void_p)), ("chunk_rows", C.POINTER(C.c_uint32)),
+                ("out", C.c_void_p), ("out_capacity", C.c_uint32), ("usr_context", C.c_void_p),
+                ("out_size", C.c_int32), ("dict_image", C.c_void_p)]
+
+
+class SpiceGpuJpegJob(C.Structure):
+    _fields_ = [("pixels", C.c_void_p), ("format", C.c_int), ("width", C.c_int), ("height", C.c_int),
+                ("stride", C.c_long), ("quality", C.c_int), ("dct", C.c_int), ("out", C.c_void_p),
+                ("out_capacity", C.c_uint32), ("out_size", C.c_int32)]
+
+
+class SpiceGpuCodecStats(C.Structure):
+    _fields_ = [("count", C.c_uint64), ("orig_bytes", C.c_uint64), ("comp_bytes", C.c_uint64),
+                ("total_ns", C.c_uint64), ("min_ns", C.c_uint64), ("max_ns", C.c_uint64)]
+
+
+class MJpegEncoderStats(C.Structure):
+    _fields_ = [("starting_bit_rate", C.c_uint64), ("cur_bit_rate", C.c_uint64),
+                ("avg_quality", C.c_double)]
+
+
+EXPORTS = [
+    "spice_gpu_init", "spice_gpu_shutdown", "spice_gpu_last_error", "spice_gpu_stream",
+    "glz_enc_dictionary_create", "glz_enc_dictionary_destroy", "glz_enc_dictionary_get_size",
+    "glz_enc_dictionary_get_restore_data", "glz_enc_dictionary_restore", "glz_enc_dictionary_reset",
+    "glz_enc_dictionary_remove_image", "glz_encoder_create", "glz_encoder_destroy", "glz_encode",
+    "mjpeg_encoder_new", "mjpeg_encoder_destroy", "mjpeg_encoder_get_bytes_per_pixel",
+    "mjpeg_encoder_start_frame", "mjpeg_encoder_encode_scanline", "mjpeg_encoder_end_frame",
+    "mjpeg_encoder_get_bit_rate", "mjpeg_encoder_get_stats",
+    "jpeg_encoder_create", "jpeg_encoder_destroy", "jpeg_encode",
+    "spice_gpu_glz_out_bound", "spice_gpu_glz_encode_batch", "spice_gpu_glz_submit",
+    "spice_gpu_glz_finish", "spice_gpu_jpeg_out_bound", "spice_gpu_jpeg_encode_batch",
+    "spice_gpu_jpeg_submit", "spice_gpu_jpeg_finish", "spice_gpu_malloc", "spice_gpu_free",
+    "spice_gpu_upload", "spice_gpu_download", "spice_gpu_get_stats", "spice_gpu_reset_stats",
+]
+
+
+class SpiceGpuError(RuntimeError):
+    pass
+
+
+class SpiceGpu:
+    """All entry points of one loaded libspicegpu, with prototypes attached."""
+
+    def __init__(self, cdll):
+        L = self.L = cdll
+        missing = [n for n in EXPORTS if not hasattr(L, n)]
+        if missing:
+            raise SpiceGpuError("libspicegpu lacks symbols: %s" % ", ".join(missing))
+        vp, u32, i = C.c_void_p, C.c_uint32, C.c_int
+        L.spice_gpu_init.restype, L.spice_gpu_init.argtypes = i, [i]
+        L.spice_gpu_last_error.restype = C.c_char_p
+        L.spice_gpu_stream.restype = vp
+        L.glz_enc_dictionary_create.restype = vp
+        L.glz_enc_dictionary_create.argtypes = [u32, u32, vp]
+        L.glz_enc_dictionary_destroy.argtypes = [vp, vp]
+        L.glz_enc_dictionary_get_size.restype, L.glz_enc_dictionary_get_size.argtypes = u32, [vp]
+        L.glz_enc_dictionary_get_restore_data.argtypes = [vp, C.POINTER(GlzEncDictRestoreData), vp]
+        L.glz_enc_dictionary_restore.restype = vp
+        L.glz_enc_dictionary_restore.argtypes = [C.POINTER(GlzEncDictRestoreData), vp]
+        L.glz_enc_dictionary_reset.argtypes = [vp, vp]
+        L.glz_enc_dictionary_remove_image.argtypes = [vp, vp, vp]
+        L.glz_encoder_create.restype, L.glz_encoder_create.argtypes = vp, [C.c_uint8, vp, vp]
+        L.glz_encoder_destroy.argtypes = [vp]
+        L.glz_encode.restype = i
+        L.glz_encode.argtypes = [vp, i, i, i, i, vp, C.c_uint, i, vp, C.c_uint, vp, C.POINTER(vp)]
+        L.mjpeg_encoder_new.restype = vp
+        L.mjpeg_encoder_new.argtypes = [i, C.c_uint64, vp, vp]
+        L.mjpeg_encoder_destroy.argtypes = [vp]
+        L.mjpeg_encoder_get_bytes_per_pixel.restype = C.c_uint8
+        L.mjpeg_encoder_get_bytes_per_pixel.argtypes = [vp]
+        L.mjpeg_encoder_start_frame.restype = i
+        L.mjpeg_encoder_start_frame.argtypes = [vp, i, i, i, C.POINTER(vp), C.POINTER(C.c_size_t), u32]
+        L.mjpeg_encoder_encode_scanline.restype = i
+        L.mjpeg_encoder_encode_scanline.argtypes = [vp, vp, C.c_size_t]
+        L.mjpeg_encoder_end_frame.restype, L.mjpeg_encoder_end_frame.argtypes = C.c_size_t, [vp]
+        L.mjpeg_encoder_get_bit_rate.restype, L.mjpeg_encoder_get_bit_rate.argtypes = C.c_uint64, [vp]
+        L.mjpeg_encoder_get_stats.argtypes = [vp, C.POINTER(MJpegEncoderStats)]
+        L.jpeg_encoder_create.restype, L.jpeg_encoder_create.argtypes = vp, [vp]
+        L.jpeg_encoder_destroy.argtypes = [vp]
+        L.jpeg_encode.restype = i
+        L.jpeg_encode.argtypes = [vp, i, i, i, i, vp, C.c_uint, i, vp, C.c_uint]
+        L.spice_gpu_glz_out_bound.restype = C.c_size_t
+        L.spice_gpu_glz_out_bound.argtypes = [i, i, i]
+        for n in ("spice_gpu_glz_encode_batch", "spice_gpu_glz_submit", "spice_gpu_glz_finish"):
+            getattr(L, n).restype = i
+            getattr(L, n).argtypes = [C.POINTER(SpiceGpuGlzJob), i]
+        L.spice_gpu_jpeg_out_bound.restype = C.c_size_t
+        L.spice_gpu_jpeg_out_bound.argtypes = [i, i]
+        for n in ("spice_gpu_jpeg_encode_batch", "spice_gpu_jpeg_submit", "spice_gpu_jpeg_finish"):
+            getattr(L, n).restype = i
+            getattr(L, n).argtypes = [C.POINTER(SpiceGpuJpegJob), i]
+        L.spice_gpu_malloc.restype, L.spice_gpu_malloc.argtypes = vp, [C.c_size_t]
+        L.spice_gpu_free.argtypes = [vp]
+        L.spice_gpu_upload.restype, L.spice_gpu_upload.argtypes = i, [vp, vp, C.c_size_t]
+        L.spice_gpu_download.restype, L.spice_gpu_download.argtypes = i, [vp, vp, C.c_size_t]
+        L.spice_gpu_get_stats.argtypes = [i, C.POINTER(SpiceGpuCodecStats)]
+
+    # ---- library state
+    def init(self, device=0):
+        if self.L.spice_gpu_init(device) != 0:
+            raise SpiceGpuError(self.last_error())
+
+    def last_error(self):
+        return (self.L.spice_gpu_last_error() or b"").decode("utf-8", "replace")
+
+    def stats(self, codec):
+        s = SpiceGpuCodecStats()
+        self.L.spice_gpu_get_stats(codec, C.byref(s))
+        return {k: getattr(s, k) for k, _ in SpiceGpuCodecStats._fields_}
+
+    # ---- device memory
+    def malloc(self, nbytes):
+        p = self.L.spice_gpu_malloc(nbytes)
+        if not p:
+            raise SpiceGpuError(self.last_error())
+        return p
+
+    def free(self, p):
+        self.L.spice_gpu_free(p)
+
+    def upload(self, dev, arr):
+        arr = np.ascontiguousarray(arr)
+        if self.L.spice_gpu_upload(dev, arr.ctypes.data, arr.nbytes) != 0:
+            raise SpiceGpuError(self.last_error())
+
+    def download(self, dev, nbytes):
+        out = np.empty(nbytes, dtype=np.uint8)
+        if nbytes and self.L.spice_gpu_download(out.ctypes.data, dev, nbytes) != 0:
+            raise SpiceGpuError(self.last_error())
+        return out
+
+    def to_device(self, arr):
+        arr = np.ascontiguousarray(arr)
+        p = self.malloc(max(arr.nbytes, 1))
+        self.upload(p, arr)
+        return p
+
+
+class _BufChain:
+    """The caller-owned chain of 64 KiB output buffers (RedCompressBuf)."""
+
+    def __init__(self, buf_size=RED_COMPRESS_BUF_SIZE):
+        self.buf_size = buf_size
+        self.bufs = []
+
+    def first(self):
+        self.bufs = [np.empty(self.buf_size, dtype=np.uint8)]
+        return self.bufs[0]
+
+    def more(self):
+        self.bufs.append(np.empty(self.buf_size, dtype=np.uint8))
+        return self.bufs[-1]
+
+    def gather(self, size):
+        # marshaller_add_compressed, server/red_worker.c:5221-5233
+        out = np.concatenate(self.bufs)[:size] if self.bufs else np.empty(0, np.uint8)
+        assert size <= len(self.bufs) * self.buf_size
+        return out.copy()
+
+
+class GlzUsr:
+    """A GlzEncoderUsrContext with the callbacks red_worker.c:5578-5794 provides."""
+
+    def __init__(self, buf_size=RED_COMPRESS_BUF_SIZE):
+        self.errors, self.warnings, self.freed_images = [], [], []
+        self.chunks, self.next_chunk, self.stride = [], 0, 0
+        self.out = _BufChain(buf_size)
+        self._libc = C.CDLL(None)
+        self._libc.malloc.restype, self._libc.malloc.argtypes = C.c_void_p, [C.c_size_t]
+        self._libc.free.argtypes = [C.c_void_p]
+
+        def on_error(usr, fmt, msg):
+            self.errors.append((msg or fmt or b"").decode("utf-8", "replace"))
+
+        def on_warn(usr, fmt, msg):
+            self.warnings.append((msg or fmt or b"").decode("utf-8", "replace"))
+
+        def on_malloc(usr, size):
+            return self._libc.malloc(size)
+
+        def on_free(usr, ptr):
+            self._libc.free(ptr)
+
+        def on_more_lines(usr, lines):
+            # encoder_usr_more_lines, server/red_worker.c:5700-5728
+            if self.next_chunk >= len(self.chunks):
+                return 0
+            c = self.chunks[self.next_chunk]
+            if c.size % self.stride:
+                return 0
+            self.next_chunk += 1
+            lines[0] = c.ctypes.data
+            return c.size // self.stride
+
+        def on_more_space(usr, io_ptr):
+            # encoder_usr_more_space, server/red_worker.c:5656-5668 (bytes for glz)
+            b = self.out.more()
+            io_ptr[0] = b.ctypes.data
+            return b.size
+
+        def on_free_image(usr, image):
+            self.freed_images.append(image)
+
+        self._cbs = (_MSG_CB(on_error), _MSG_CB(on_warn), _MSG_CB(on_warn), _MALLOC_CB(on_malloc),
+                     _FREE_CB(on_free), _LINES_CB(on_more_lines), _SPACE_CB(on_more_space),
+                     _FREE_IMAGE_CB(on_free_image))
+        self.ctx = GlzEncoderUsrContext(*self._cbs)
+
+    @property
+    def ptr(self):
+        return C.addressof(self.ctx)
+
+
+class GlzDictionary:
+    def __init__(self, gpu, size_px, max_encoders=4, usr=None, restore=None):
+        self.gpu, self.usr = gpu, usr or GlzUsr()
+        if restore is None:
+            self.h = gpu.L.glz_enc_dictionary_create(size_px, max_encoders, self.usr.ptr)
+        else:
+            self.h = gpu.L.glz_enc_dictionary_restore(C.byref(restore), self.usr.ptr)
+        if not self.h:
+            raise SpiceGpuError("glz_enc_dictionary_create failed: " + gpu.last_error())
+
+    def close(self):
+        if self.h:
+            self.gpu.L.glz_enc_dictionary_destroy(self.h, self.usr.ptr)
+            self.h = None
+
+    def get_size(self):
+        return self.gpu.L.glz_enc_dictionary_get_size(self.h)
+
+    def get_restore_data(self):
+        d = GlzEncDictRestoreData()
+        self.gpu.L.glz_enc_dictionary_get_restore_data(self.h, C.byref(d), self.usr.ptr)
+        return d
+
+    def reset(self):
+        self.gpu.L.glz_enc_dictionary_reset(self.h, self.usr.ptr)
+
+    def remove_image(self, image):
+        self.gpu.L.glz_enc_dictionary_remove_image(self.h, image, self.usr.ptr)
+
+
+class GlzEncoder:
+    def __init__(self, gpu, dictionary, enc_id=0, usr=None):
+        self.gpu, self.dict, self.usr = gpu, dictionary, usr or dictionary.usr
+        self.h = gpu.L.glz_encoder_create(enc_id, dictionary.h, self.usr.ptr)
+        if not self.h:
+            raise SpiceGpuError("glz_encoder_create failed")
+
+    def close(self):
+        if self.h:
+            self.gpu.L.glz_encoder_destroy(self.h)
+            self.h = None
+
+    def encode(self, img_type, width, height, stride, chunks, top_down=True, usr_context=0,
+               first_lines_direct=False):
+        """red_glz_compress_image's call (server/red_worker.c:6034-6045): rows come
+        through more_lines unless first_lines_direct hands chunk 0 in directly."""
+        u = self.usr
+        u.chunks = [np.ascontiguousarray(c, dtype=np.uint8).reshape(-1) for c in chunks]
+        u.stride = stride
+        u.next_chunk = 0
+        lines, num_lines = None, 0
+        if first_lines_direct:
+            lines, num_lines = u.chunks[0].ctypes.data, u.chunks[0].size // stride
+            u.next_chunk = 1
+        first = u.out.first()
+        image = C.c_void_p()
+        n_err = len(u.errors)
+        size = self.gpu.L.glz_encode(self.h, img_type, width, height, 1 if top_down else 0, lines,
+                                     num_lines, stride, first.ctypes.data, first.size, usr_context,
+                                     C.byref(image))
+        if len(u.errors) > n_err or size <= 0:
+            raise SpiceGpuError("glz_encode: " + "; ".join(u.errors[n_err:] or [self.gpu.last_error()]))
+        return u.out.gather(size), image.value
+
+
+class MJpegEncoder:
+    """mjpeg_encoder_new/start_frame/encode_scanline/end_frame (server/mjpeg_encoder.h)."""
+
+    def __init__(self, gpu):
+        self.gpu = gpu
+        self.h = gpu.L.mjpeg_encoder_new(0, 0, None, None)
+        if not self.h:
+            raise SpiceGpuError("mjpeg_encoder_new failed: " + gpu.last_error())
+        self._dest = C.c_void_p(None)
+        self._dest_len = C.c_size_t(0)
+        self._libc = C.CDLL(None)
+        self._libc.free.argtypes = [C.c_void_p]
+
+    def close(self):
+        if self.h:
+            self.gpu.L.mjpeg_encoder_destroy(self.h)
+            self.h = None
+        if self._dest.value:
+            self._libc.free(self._dest)
+            self._dest = C.c_void_p(None)
+
+    def encode_frame(self, fmt, width, height, rows, stride):
+        """encode_frame of server/red_worker.c:8341-8377: one scanline call per row."""
+        L = self.gpu.L
+        rows = np.ascontiguousarray(rows, dtype=np.uint8).reshape(-1)
+        r = L.mjpeg_encoder_start_frame(self.h, fmt, width, height, C.byref(self._dest),
+                                        C.byref(self._dest_len), 0)
+        if r != MJPEG_ENCODER_FRAME_ENCODE_START:
+            raise SpiceGpuError("mjpeg_encoder_start_frame returned %d" % r)
+        base = rows.ctypes.data
+        for y in range(height):
+            if L.mjpeg_encoder_encode_scanline(self.h, base + y * stride, width) == 0:
+                raise SpiceGpuError("mjpeg_encoder_encode_scanline failed")
+        n = L.mjpeg_encoder_end_frame(self.h)
+        if n == 0:
+            raise SpiceGpuError("mjpeg_encoder_end_frame: " + self.gpu.last_error())
+        return np.ctypeslib.as_array(C.cast(self._dest, C.POINTER(C.c_uint8)), shape=(n,)).copy()
+
+
+class JpegEncoder:
+    """jpeg_encoder_create / jpeg_encode (server/jpeg_encoder.h) with red_worker's callbacks."""
+
+    def __init__(self, gpu, buf_size=RED_COMPRESS_BUF_SIZE):
+        self.gpu = gpu
+        self.out = _BufChain(buf_size)
+        self.chunks, self.next_chunk, self.stride, self.reverse = [], 0, 0, False
+
+        def on_more_space(usr, io_ptr):
+            b = self.out.more()
+            io_ptr[0] = b.ctypes.data
+            return b.size
+
+        def on_more_lines(usr, lines):
+            # encoder_usr_more_lines incl. the bottom-up walk, server/red_worker.c:5700-5728
+            if self.reverse:
+                if self.next_chunk < 0:
+                    return 0
+                c = self.chunks[self.next_chunk]
+                self.next_chunk -= 1
+                lines[0] = c.ctypes.data + c.size - self.stride
+            else:
+                if self.next_chunk >= len(self.chunks):
+                    return 0
+                c = self.chunks[self.next_chunk]
+                self.next_chunk += 1
+                lines[0] = c.ctypes.data
+            return c.size // self.stride
+
+        self._cbs = (_SPACE_CB(on_more_space), _LINES_CB(on_more_lines))
+        self.ctx = JpegEncoderUsrContext(*self._cbs)
+        self.h = gpu.L.jpeg_encoder_create(C.addressof(self.ctx))
+        if not self.h:
+            raise SpiceGpuError("jpeg_encoder_create failed")
+
+    def close(self):
+        if self.h:
+            self.gpu.L.jpeg_encoder_destroy(self.h)
+            self.h = None
+
+    def encode(self, quality, img_type, width, height, stride, chunks, top_down=True):
+        """red_jpeg_compress_image's call (server/red_worker.c:6243-6262)."""
+        self.chunks = [np.ascontiguousarray(c, dtype=np.uint8).reshape(-1) for c in chunks]
+        self.stride = stride
+        self.reverse = not top_down
+        self.next_chunk = len(self.chunks) - 1 if self.reverse else 0
+        first = self.out.first()
+        n = self.gpu.L.jpeg_encode(self.h, quality, img_type, width, height, None, 0,
+                                   -stride if self.reverse else stride, first.ctypes.data, first.size)
+        if n <= 0:
+            raise SpiceGpuError("jpeg_encode: " + self.gpu.last_error())
+        return self.out.gather(n)
+
+
+def glz_encode_batch(gpu, items, split=False):
+    """Device-resident batch: items are dicts with encoder (GlzEncoder), type,
+    width, height, stride, top_down, chunks (device pointers), chunk_rows, out
+    (device pointer), out_capacity.  Returns the list of sizes."""
+    n = len(items)
+    jobs = (SpiceGpuGlzJob * n)()
+    keep = []
+    for j, it in enumerate(items):
+        nch = len(it["chunks"])
+        ptrs = (C.c_void_p * nch)(*it["chunks"])
+        rows = (C.c_uint32 * nch)(*it["chunk_rows"])
+        keep.append((ptrs, rows))
+        jobs[j].encoder = it["encoder"].h
+        jobs[j].type = it["type"]
+        jobs[j].width, jobs[j].height = it["width"], it["height"]
+        jobs[j].top_down, jobs[j].stride = int(it.get("top_down", 1)), it["stride"]
+        jobs[j].nchunks = nch
+        jobs[j].chunk_ptrs = ptrs
+        jobs[j].chunk_rows = rows
+        jobs[j].out, jobs[j].out_capacity = it["out"], it["out_capacity"]
+        jobs[j].usr_context = it.get("usr_context", 0)
+    if split:
+        rc = gpu.L.spice_gpu_glz_submit(jobs, n)
+        if rc == 0:
+            rc = gpu.L.spice_gpu_glz_finish(jobs, n)
+    else:
+        rc = gpu.L.spice_gpu_glz_encode_batch(jobs, n)
+    if rc != 0:
+        raise SpiceGpuError("glz batch: " + gpu.last_error())
+    return [jobs[j].out_size for j in range(n)], [jobs[j].dict_image for j in range(n)]
+
+
+def jpeg_encode_batch(gpu, items):
+    """Device-resident batch of frames; items are dicts with pixels (device
+    pointer), format, width, height, stride, quality, dct, out, out_capacity."""
+    n = len(items)
+    jobs = (SpiceGpuJpegJob * n)()
+    for j, it in enumerate(items):
+        jobs[j].pixels, jobs[j].format = it["pixels"], it["format"]
+        jobs[j].width, jobs[j].height, jobs[j].stride = it["width"], it["height"], it["stride"]
+        jobs[j].quality, jobs[j].dct = it["quality"], it["dct"]
+        jobs[j].out, jobs[j].out_capacity = it["out"], it["out_capacity"]
+    if gpu.L.spice_gpu_jpeg_encode_batch(jobs, n) != 0:
+        raise SpiceGpuError("jpeg batch: " + gpu.last_error())
+    return [jobs[j].out_size for j in range(n)]

@@ -1,0 +1,1007 @@
+/*
+ * GLZ: host bookkeeping of the shared dictionary and the C entry points.
+ *
+ * The window of images/segments is pure control state (a few words per image)
+ * and stays on the host, following server/glz_encoder_dictionary.c step by
+ * step so that segment slots, image ids and eviction points are the ones the
+ * reference would produce -- the hash table in HBM stores segment slot numbers,
+ * and a recycled slot is a legitimate match source (the reference never clears
+ * the table on eviction), so slot reuse order is part of the bitstream.
+ * Pixels, the hash table and the device view of the segment table live in HBM.
+ *
+ * Encodes on one dictionary are serialised by its mutex; with that, a
+ * dictionary is never "in use" by another encoder when an image is added
+ * (glz_encoder_dictionary.c:569-571), which is the only regime in which the
+ * reference's output is defined independently of thread timing.
+ */
+#include <string.h>
+
+#include <mutex>
+#include <vector>
+
+#include "glz_device.h"
+#include "runtime.h"
+
+using namespace spicegpu;
+
+void glz_launch_parse(const GlzDevJob *jobs, int njobs, const uint32_t *u32_pool,
+                      const GlzDevSegUpdate *upd_pool, hipStream_t stream);
+void glz_launch_copy(const GlzCopyDesc *descs, int ndescs, unsigned blocks_per_desc,
+                     hipStream_t stream);
+
+namespace {
+
+const uint32_t kNullSeg = 0xffffffffu;      /* glz_encoder_dictionary_protected.h:55-56 */
+const uint32_t kInitSegs = 1000;            /* glz_encoder_dictionary_protected.h:57 */
+const uint32_t kMaxWindow = 1u << 25;       /* LZ_MAX_WINDOW_SIZE, client/red_client.cpp:875 */
+
+const int kTypeIsRgb[12] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1};
+const int kTypeIsPlt[12] = {0, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0};
+const int kPltPixelsPerByte[12] = {0, 8, 8, 2, 2, 1, 0, 0, 0, 0, 0, 0};
+const int kRgbBytesPerPixel[12] = {0, 1, 1, 1, 1, 1, 2, 3, 4, 4, 4, 1};
+
+struct HostImage {
+    uint64_t id;
+    int type;
+    int size; /* pixels */
+    uint32_t first_seg;
+    GlzUsrImageContext *usr_context;
+    HostImage *next;
+    bool alive;
+    uint64_t arena_begin, arena_end;
+};
+
+struct HostSeg {
+    HostImage *image;
+    uint64_t arena_off;
+    uint32_t nunits;
+    uint32_t pixels_num;
+    uint64_t pixels_so_far;
+    uint32_t next;
+};
+
+struct Dict {
+    std::recursive_mutex lock; /* free_image callbacks may call back into the dictionary */
+    uint32_t size_limit = 0;
+    uint32_t max_encoders = 0;
+    uint64_t last_image_id = 0;
+    uint64_t pixels_so_far = 0;
+    std::vector<HostSeg> segs;
+    uint32_t used_segs_head = kNullSeg, used_segs_tail = kNullSeg, free_segs_head = kNullSeg;
+    std::vector<uint32_t> encoders_heads;
+    HostImage *used_images_head = nullptr, *used_images_tail = nullptr, *free_images = nullptr;
+    GlzEncoderUsrContext *cur_usr = nullptr;
+
+    /* HBM side */
+    uint8_t *d_arena = nullptr;
+    uint64_t arena_cap = 0;
+    uint2 *d_htab = nullptr;
+    GlzDevSeg *d_segs = nullptr;
+    uint32_t d_segs_cap = 0;
+    std::vector<uint32_t> dirty; /* segment slots whose device copy is stale */
+
+    /* FIFO ring allocator over the arena */
+    uint64_t ring_head = 0, ring_tail = 0;
+    bool ring_wrapped = false;
+};
+
+struct Encoder {
+    GlzEncoderUsrContext *usr;
+    uint8_t id;
+    Dict *dict;
+    DevBuffer out;       /* compressed stream of the synchronous path */
+    PinnedBuffer bounce; /* its host landing zone */
+};
+
+uint64_t align16(uint64_t v)
+{
+    return (v + 15) & ~15ull;
+}
+
+/* ------------------------------------------------------------ ring allocator
+ * Images leave the window oldest first, so their pixel runs form a FIFO. */
+bool ring_alloc(Dict *d, uint64_t bytes, uint64_t *at)
+{
+    if (!d->used_images_head) {
+        d->ring_head = d->ring_tail = 0;
+        d->ring_wrapped = false;
+    }
+    if (!d->ring_wrapped) {
+        if (d->arena_cap - d->ring_tail >= bytes) {
+            *at = d->ring_tail;
+            d->ring_tail += bytes;
+            return true;
+        }
+        if (d->ring_head >= bytes) {
+            *at = 0;
+            d->ring_tail = bytes;
+            d->ring_wrapped = true;
+            return true;
+        }
+        return false;
+    }
+    if (d->ring_head - d->ring_tail >= bytes) {
+        *at = d->ring_tail;
+        d->ring_tail += bytes;
+        return true;
+    }
+    return false;
+}
+
+void ring_after_free(Dict *d, uint64_t freed_begin)
+{
+    if (!d->used_images_head) {
+        d->ring_head = d->ring_tail = 0;
+        d->ring_wrapped = false;
+        return;
+    }
+    uint64_t nh = d->used_images_head->arena_begin;
+    if (d->ring_wrapped && nh < freed_begin) {
+        d->ring_wrapped = false;
+    }
+    d->ring_head = nh;
+}
+
+/* -------------------------------------------------- device view of a segment */
+GlzDevSeg dev_view(const Dict *d, const HostSeg &s)
+{
+    GlzDevSeg v;
+    memset(&v, 0, sizeof(v));
+    v.pixels_so_far = s.pixels_so_far;
+    v.arena_off16 = (uint32_t)(s.arena_off >> 4);
+    v.nunits = s.nunits;
+    if (s.image) {
+        const HostSeg &first = d->segs[s.image->first_seg];
+        v.image_id = s.image->id;
+        v.img_first_delta = (uint32_t)(s.pixels_so_far - first.pixels_so_far);
+        v.flags = (uint32_t)s.image->type | GLZ_SEG_USED | (s.image->alive ? GLZ_SEG_ALIVE : 0u);
+    }
+    return v;
+}
+
+void mark_image_dirty(Dict *d, HostImage *im)
+{
+    for (uint32_t sid = im->first_seg; sid != kNullSeg && d->segs[sid].image == im;
+         sid = d->segs[sid].next) {
+        d->dirty.push_back(sid);
+    }
+}
+
+/* ------------------------------------------------------------ window upkeep */
+void blank_seg(HostSeg &s, uint32_t next)
+{
+    s.image = nullptr;
+    s.arena_off = 0;
+    s.nunits = 0;
+    s.pixels_num = 0;
+    s.pixels_so_far = 0;
+    s.next = next;
+}
+
+/* glz_encoder_dictionary.c:30-45 */
+void release_all_images(Dict *d)
+{
+    while (d->used_images_head) {
+        HostImage *im = d->used_images_head;
+        d->used_images_head = im->next;
+        if (im->alive && d->cur_usr && d->cur_usr->free_image) {
+            d->cur_usr->free_image(d->cur_usr, im->usr_context);
+        }
+        im->next = d->free_images;
+        im->alive = false;
+        d->free_images = im;
+    }
+    d->used_images_tail = nullptr;
+}
+
+bool ensure_dev_segs(Dict *d)
+{
+    uint32_t need = (uint32_t)d->segs.size();
+    if (need <= d->d_segs_cap) {
+        return true;
+    }
+    GlzDevSeg *n = nullptr;
+    if (!check(hipMalloc((void **)&n, sizeof(GlzDevSeg) * (size_t)need), "hipMalloc segs")) {
+        return false;
+    }
+    hipStream_t st = stream();
+    bool ok = check(hipMemsetAsync(n, 0, sizeof(GlzDevSeg) * (size_t)need, st), "memset segs");
+    if (ok && d->d_segs) {
+        ok = check(hipMemcpyAsync(n, d->d_segs, sizeof(GlzDevSeg) * (size_t)d->d_segs_cap,
+                                  hipMemcpyDeviceToDevice, st), "copy segs");
+    }
+    ok = ok && check(hipStreamSynchronize(st), "sync");
+    if (!ok) {
+        hipFree(n);
+        return false;
+    }
+    if (d->d_segs) {
+        hipFree(d->d_segs);
+    }
+    d->d_segs = n;
+    d->d_segs_cap = need;
+    return true;
+}
+
+/* glz_encoder_dictionary.c:82-117,203-212 */
+bool dict_reset(Dict *d)
+{
+    d->last_image_id = 0;
+    d->free_segs_head = 0;
+    for (uint32_t i = 0; i < d->segs.size(); i++) {
+        blank_seg(d->segs[i], i + 1);
+    }
+    d->segs.back().next = kNullSeg;
+    d->used_segs_head = d->used_segs_tail = kNullSeg;
+    for (auto &h : d->encoders_heads) {
+        h = kNullSeg;
+    }
+    release_all_images(d);
+    d->dirty.clear();
+    d->ring_head = d->ring_tail = 0;
+    d->ring_wrapped = false;
+    hipStream_t st = stream();
+    std::lock_guard<std::mutex> dev(device_mutex());
+    return check(hipMemsetAsync(d->d_htab, 0, sizeof(uint2) * (size_t)GLZ_HASH_SIZE, st), "memset htab") &&
+           check(hipMemsetAsync(d->d_segs, 0, sizeof(GlzDevSeg) * (size_t)d->d_segs_cap, st), "memset segs") &&
+           check(hipStreamSynchronize(st), "sync");
+}
+
+void dict_free_device(Dict *d)
+{
+    if (d->d_arena) hipFree(d->d_arena);
+    if (d->d_htab) hipFree(d->d_htab);
+    if (d->d_segs) hipFree(d->d_segs);
+    d->d_arena = nullptr;
+    d->d_htab = nullptr;
+    d->d_segs = nullptr;
+}
+
+/* glz_encoder_dictionary.c:267-309 */
+void grow_segs(Dict *d)
+{
+    uint32_t old = (uint32_t)d->segs.size(), quota = old * 2;
+    d->segs.resize(quota);
+    for (uint32_t i = old; i < quota; i++) {
+        blank_seg(d->segs[i], i + 1);
+    }
+    d->segs[quota - 1].next = d->free_segs_head;
+    d->free_segs_head = old;
+}
+
+/* glz_encoder_dictionary.c:312-336 */
+HostImage *take_image(Dict *d)
+{
+    HostImage *im;
+    if (d->free_images) {
+        im = d->free_images;
+        d->free_images = im->next;
+    } else {
+        im = new HostImage();
+    }
+    im->next = nullptr;
+    if (d->used_images_tail) {
+        d->used_images_tail->next = im;
+    }
+    d->used_images_tail = im;
+    if (!d->used_images_head) {
+        d->used_images_head = im;
+    }
+    return im;
+}
+
+/* glz_encoder_dictionary.c:339-356 */
+uint32_t take_seg(Dict *d)
+{
+    if (d->free_segs_head == kNullSeg) {
+        grow_segs(d);
+    }
+    uint32_t id = d->free_segs_head;
+    d->free_segs_head = d->segs[id].next;
+    return id;
+}
+
+/* glz_encoder_dictionary.c:392-424 */
+HostImage *head_after_adding(Dict *d, int new_size)
+{
+    if (!d->used_images_head) {
+        return nullptr;
+    }
+    HostImage *head = d->segs[d->used_segs_head].image;
+    uint32_t win = d->segs[d->used_segs_tail].pixels_num +
+                   (uint32_t)(d->segs[d->used_segs_tail].pixels_so_far -
+                              d->segs[d->used_segs_head].pixels_so_far);
+    while (win + (uint32_t)new_size > d->size_limit) {
+        win -= (uint32_t)head->size;
+        head = head->next;
+    }
+    return head;
+}
+
+bool dict_in_use(Dict *d)
+{
+    for (uint32_t h : d->encoders_heads) {
+        if (h != kNullSeg) {
+            return true;
+        }
+    }
+    return false;
+}
+
+/* glz_encoder_dictionary.c:359-387,439-459 */
+void drop_head_until(Dict *d, HostImage *end_image)
+{
+    while (d->used_images_head != end_image) {
+        HostImage *im = d->used_images_head;
+        uint32_t old_free = d->free_segs_head, sid, nxt;
+        d->free_segs_head = im->first_seg;
+        for (sid = im->first_seg, nxt = d->segs[sid].next;
+             nxt != kNullSeg && d->segs[nxt].image == im; sid = nxt, nxt = d->segs[sid].next) {
+        }
+        d->segs[sid].next = old_free;
+        d->used_images_head = im->next;
+        if (im->alive && d->cur_usr && d->cur_usr->free_image) {
+            d->cur_usr->free_image(d->cur_usr, im->usr_context);
+        }
+        im->alive = false;
+        im->next = d->free_images;
+        d->free_images = im;
+        ring_after_free(d, im->arena_begin);
+    }
+    if (!d->used_images_head) {
+        d->used_segs_head = d->used_segs_tail = kNullSeg;
+        d->used_images_tail = nullptr;
+    } else {
+        d->used_segs_head = end_image->first_seg;
+    }
+}
+
+bool seg_earlier(Dict *d, uint32_t dst, uint32_t src)
+{
+    return src == kNullSeg ||
+           (dst != kNullSeg && d->segs[dst].pixels_so_far < d->segs[src].pixels_so_far);
+}
+
+/* glz_encoder_dictionary.c:593-633 */
+void post_encode(Dict *d, uint32_t enc_id)
+{
+    uint32_t early = kNullSeg;
+    for (uint32_t i = 0; i < d->max_encoders; i++) {
+        if (i != enc_id && seg_earlier(d, d->encoders_heads[i], early)) {
+            early = d->encoders_heads[i];
+        }
+    }
+    if (seg_earlier(d, d->used_segs_head, early)) {
+        early = d->used_segs_head;
+    }
+    uint32_t mine = d->encoders_heads[enc_id];
+    if (seg_earlier(d, mine, early)) {
+        drop_head_until(d, d->segs[early].image);
+    }
+    d->encoders_heads[enc_id] = kNullSeg;
+}
+
+/* ------------------------------------------------ one image, ready to launch */
+struct Chunk {
+    const uint8_t *ptr;
+    uint32_t rows;
+};
+
+struct Prepared {
+    Encoder *enc = nullptr;
+    HostImage *image = nullptr;
+    GlzDevJob dev;
+    std::vector<uint32_t> seg_list;
+    std::vector<GlzDevSegUpdate> updates;
+    std::vector<GlzCopyDesc> copies; /* src -> arena, in segment order */
+    uint64_t raw_bytes = 0;
+};
+
+const char *validate(LzImageType type, int width, int height, int stride)
+{
+    if (type <= LZ_IMAGE_TYPE_INVALID || type > LZ_IMAGE_TYPE_RGBA) {
+        return "bad image type\n"; /* glz_encoder.c:299-302 */
+    }
+    if (kTypeIsPlt[type]) {
+        /* red_worker.c:6012 only ever hands RGB bitmaps to GLZ */
+        return "palette images are not handled by the GPU GLZ path\n";
+    }
+    if (width <= 0 || height <= 0) {
+        return "bad image size\n";
+    }
+    if (stride != width * kRgbBytesPerPixel[type]) {
+        return "stride != width*bytes_per_pixel (rgb)\n"; /* glz_encoder.c:243-247 */
+    }
+    return nullptr;
+}
+
+/* glz_dictionary_pre_encode (glz_encoder_dictionary.c:550-591) plus the launch
+ * description.  Called with the dictionary locked. */
+const char *prepare(Encoder *enc, LzImageType type, int width, int height, int top_down,
+                    int stride, const std::vector<Chunk> &chunks, GlzUsrImageContext *usr_context,
+                    uint8_t *d_out, uint32_t out_cap, Prepared *p)
+{
+    Dict *d = enc->dict;
+    d->cur_usr = enc->usr;
+
+    int image_size = kTypeIsRgb[type] ? height * stride / kRgbBytesPerPixel[type]
+                                      : height * stride * kPltPixelsPerByte[type];
+    if ((uint32_t)image_size > d->size_limit) {
+        return "image is bigger than window\n"; /* glz_encoder_dictionary.c:397-399 */
+    }
+    uint32_t rows_total = 0;
+    for (const Chunk &c : chunks) {
+        rows_total += c.rows;
+    }
+    if (chunks.empty() || rows_total < (uint32_t)height) {
+        return "more lines failed\n"; /* glz_encoder_dictionary.c:497-501,517-520 */
+    }
+
+    HostImage *new_head = head_after_adding(d, image_size);
+    if (!dict_in_use(d)) {
+        drop_head_until(d, new_head);
+    }
+
+    /* arena room for every chunk, each starting on a 16-byte boundary */
+    uint64_t need = 0;
+    uint32_t row = 0;
+    size_t nseg = 0;
+    for (const Chunk &c : chunks) {
+        need += align16((uint64_t)c.rows * (uint64_t)stride);
+        row += c.rows;
+        nseg++;
+        if (row >= (uint32_t)height) {
+            break;
+        }
+    }
+    uint64_t at = 0;
+    if (!ring_alloc(d, need, &at)) {
+        return "window arena exhausted\n";
+    }
+
+    /* glz_encoder_dictionary.c:480-548 */
+    HostImage *im = take_image(d);
+    im->id = d->last_image_id++;
+    im->size = image_size;
+    im->type = type;
+    im->usr_context = usr_context;
+    im->arena_begin = at;
+    im->arena_end = at + need;
+
+    const int bpp = kRgbBytesPerPixel[type];
+    uint32_t sid = kNullSeg, prev = kNullSeg;
+    row = 0;
+    uint64_t off = at;
+    for (size_t c = 0; c < nseg; c++) {
+        uint64_t bytes = (uint64_t)chunks[c].rows * (uint64_t)stride;
+        sid = take_seg(d);
+        HostSeg &s = d->segs[sid];
+        s.image = im;
+        s.arena_off = off;
+        s.nunits = (uint32_t)(bytes / (uint64_t)bpp);
+        s.pixels_num = (uint32_t)((int64_t)image_size * chunks[c].rows / height);
+        s.pixels_so_far = d->pixels_so_far;
+        d->pixels_so_far += s.pixels_num;
+        s.next = kNullSeg;
+        if (row == 0) {
+            im->first_seg = sid;
+        } else {
+            d->segs[prev].next = sid;
+        }
+        row += chunks[c].rows;
+        prev = sid;
+        p->seg_list.push_back(sid);
+        GlzCopyDesc cd;
+        cd.src = chunks[c].ptr;
+        cd.dst = d->d_arena + off;
+        cd.bytes = bytes;
+        p->copies.push_back(cd);
+        p->raw_bytes += bytes;
+        off += align16(bytes);
+    }
+    if (d->used_segs_tail == kNullSeg) {
+        d->used_segs_head = im->first_seg;
+        d->used_segs_tail = sid;
+    } else {
+        d->segs[d->used_segs_tail].next = im->first_seg;
+        d->used_segs_tail = sid;
+    }
+    im->alive = true;
+    for (uint32_t s : p->seg_list) {
+        d->dirty.push_back(s);
+    }
+
+    uint32_t head_dist;
+    if (new_head) {
+        d->encoders_heads[enc->id] = new_head->first_seg;
+        head_dist = (uint32_t)(im->id - new_head->id);
+    } else {
+        d->encoders_heads[enc->id] = im->first_seg;
+        head_dist = 0;
+    }
+
+    if (!ensure_dev_segs(d)) {
+        return "device segment table allocation failed\n";
+    }
+    for (uint32_t s : d->dirty) {
+        GlzDevSegUpdate u;
+        memset(&u, 0, sizeof(u));
+        u.index = s;
+        u.seg = dev_view(d, d->segs[s]);
+        p->updates.push_back(u);
+    }
+    d->dirty.clear();
+
+    p->enc = enc;
+    p->image = im;
+    memset(&p->dev, 0, sizeof(p->dev));
+    p->dev.arena = d->d_arena;
+    p->dev.htab = d->d_htab;
+    p->dev.segs = d->d_segs;
+    p->dev.out = d_out;
+    p->dev.out_cap = out_cap;
+    p->dev.image_id = im->id;
+    p->dev.head_psf = d->segs[d->encoders_heads[enc->id]].pixels_so_far;
+    p->dev.type = (uint32_t)type;
+    p->dev.width = (uint32_t)width;
+    p->dev.height = (uint32_t)height;
+    p->dev.stride = (uint32_t)stride;
+    p->dev.top_down = top_down ? 1u : 0u;
+    p->dev.win_head_dist = head_dist;
+    p->dev.nsegs = (uint32_t)p->seg_list.size();
+    p->dev.nupd = (uint32_t)p->updates.size();
+    return nullptr;
+}
+
+/* Batch in flight between submit and finish (guarded by device_mutex). */
+struct Flight {
+    std::vector<Prepared> jobs;
+    std::vector<std::unique_lock<std::recursive_mutex>> dict_locks;
+    std::unique_lock<std::mutex> dev_lock;
+    Staging staging;
+    size_t results_off = 0;
+    bool active = false;
+    uint64_t t0 = 0;
+};
+Flight g_flight;
+
+/* Lays jobs, pools and copy descriptors out in the staging buffer, uploads
+ * them and enqueues copy + parse.  copy_on_device: the chunk sources are
+ * device pointers (batch path); otherwise the caller has already enqueued
+ * host-to-arena copies on the stream. */
+bool launch(std::vector<Prepared> &jobs, Staging &st, size_t *results_off, bool copy_on_device)
+{
+    size_t n = jobs.size();
+    size_t off_jobs = 0;
+    size_t off_u32 = off_jobs + sizeof(GlzDevJob) * n;
+    size_t n_u32 = 0, n_upd = 0, n_copy = 0;
+    for (Prepared &p : jobs) {
+        n_u32 += p.seg_list.size();
+        n_upd += p.updates.size();
+        n_copy += p.copies.size();
+    }
+    size_t off_upd = (off_u32 + sizeof(uint32_t) * n_u32 + 15) & ~(size_t)15;
+    size_t off_copy = off_upd + sizeof(GlzDevSegUpdate) * n_upd;
+    size_t off_res = off_copy + sizeof(GlzCopyDesc) * n_copy;
+    size_t total = off_res + sizeof(int32_t) * n;
+    if (!st.reserve(total)) {
+        return false;
+    }
+    uint32_t *u32 = (uint32_t *)(st.host + off_u32);
+    GlzDevSegUpdate *upd = (GlzDevSegUpdate *)(st.host + off_upd);
+    GlzCopyDesc *cp = (GlzCopyDesc *)(st.host + off_copy);
+    GlzDevJob *dj = (GlzDevJob *)(st.host + off_jobs);
+    size_t iu = 0, iup = 0, ic = 0;
+    uint64_t max_copy = 0;
+    for (size_t j = 0; j < n; j++) {
+        Prepared &p = jobs[j];
+        p.dev.seg_list_off = (uint32_t)iu;
+        p.dev.upd_off = (uint32_t)iup;
+        p.dev.result = (int32_t *)(st.dev + off_res) + j;
+        for (uint32_t s : p.seg_list) u32[iu++] = s;
+        for (const GlzDevSegUpdate &u : p.updates) upd[iup++] = u;
+        for (const GlzCopyDesc &c : p.copies) {
+            cp[ic++] = c;
+            max_copy = c.bytes > max_copy ? c.bytes : max_copy;
+        }
+        dj[j] = p.dev;
+    }
+    hipStream_t s = stream();
+    if (!check(hipMemcpyAsync(st.dev, st.host, off_res, hipMemcpyHostToDevice, s), "upload jobs")) {
+        return false;
+    }
+    if (copy_on_device && n_copy) {
+        uint64_t per_block = 256ull * 16 * 8; /* 8 vectors per lane */
+        unsigned blocks = (unsigned)((max_copy + per_block - 1) / per_block);
+        blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+        glz_launch_copy((const GlzCopyDesc *)(st.dev + off_copy), (int)n_copy, blocks, s);
+    }
+    glz_launch_parse((const GlzDevJob *)(st.dev + off_jobs), (int)n,
+                     (const uint32_t *)(st.dev + off_u32),
+                     (const GlzDevSegUpdate *)(st.dev + off_upd), s);
+    if (!check(hipGetLastError(), "glz launch")) {
+        return false;
+    }
+    if (!check(hipMemcpyAsync(st.host + off_res, st.dev + off_res, sizeof(int32_t) * n,
+                              hipMemcpyDeviceToHost, s), "download results")) {
+        return false;
+    }
+    *results_off = off_res;
+    return true;
+}
+
+void usr_error(GlzEncoderUsrContext *usr, const char *msg)
+{
+    set_error("glz: %s", msg);
+    if (usr && usr->error) {
+        usr->error(usr, "%s", msg);
+    }
+}
+
+} // namespace
+
+/* ====================================================================== C ABI */
+extern "C" {
+
+GlzEncDictContext *glz_enc_dictionary_create(uint32_t size, uint32_t max_encoders,
+                                             GlzEncoderUsrContext *usr)
+{
+    if (size > kMaxWindow || max_encoders == 0 || !ensure_init()) {
+        if (size > kMaxWindow) {
+            set_error("glz: window of %u pixels exceeds the 2^25 cap", size);
+        }
+        return nullptr;
+    }
+    Dict *d = new Dict();
+    d->cur_usr = usr;
+    d->size_limit = size;
+    d->max_encoders = max_encoders;
+    d->segs.resize(kInitSegs);
+    d->encoders_heads.assign(max_encoders, kNullSeg);
+    /* FIFO ring: twice the window (in its widest pixel format) always has room
+     * for the next image once the head images it displaces are gone */
+    d->arena_cap = 2ull * (uint64_t)size * 4ull + (4ull << 20);
+    bool ok = check(hipMalloc((void **)&d->d_arena, d->arena_cap + 64), "hipMalloc arena") &&
+              check(hipMalloc((void **)&d->d_htab, sizeof(uint2) * (size_t)GLZ_HASH_SIZE), "hipMalloc htab");
+    ok = ok && ensure_dev_segs(d);
+    if (!ok || !dict_reset(d)) {
+        dict_free_device(d);
+        delete d;
+        return nullptr;
+    }
+    return (GlzEncDictContext *)d;
+}
+
+void glz_enc_dictionary_destroy(GlzEncDictContext *opaque_dict, GlzEncoderUsrContext *usr)
+{
+    Dict *d = (Dict *)opaque_dict;
+    if (!d) {
+        return;
+    }
+    d->cur_usr = usr;
+    release_all_images(d);
+    while (d->free_images) {
+        HostImage *im = d->free_images;
+        d->free_images = im->next;
+        delete im;
+    }
+    dict_free_device(d);
+    delete d;
+}
+
+uint32_t glz_enc_dictionary_get_size(GlzEncDictContext *opaque_dict)
+{
+    return opaque_dict ? ((Dict *)opaque_dict)->size_limit : 0;
+}
+
+void glz_enc_dictionary_get_restore_data(GlzEncDictContext *opaque_dict,
+                                         GlzEncDictRestoreData *out_data,
+                                         GlzEncoderUsrContext *usr)
+{
+    Dict *d = (Dict *)opaque_dict;
+    d->cur_usr = usr;
+    out_data->last_image_id = d->last_image_id;
+    out_data->max_encoders = d->max_encoders;
+    out_data->size = d->size_limit;
+}
+
+GlzEncDictContext *glz_enc_dictionary_restore(GlzEncDictRestoreData *restore_data,
+                                              GlzEncoderUsrContext *usr)
+{
+    if (!restore_data) {
+        return nullptr;
+    }
+    Dict *d = (Dict *)glz_enc_dictionary_create(restore_data->size, restore_data->max_encoders, usr);
+    if (d) {
+        d->last_image_id = restore_data->last_image_id;
+    }
+    return (GlzEncDictContext *)d;
+}
+
+void glz_enc_dictionary_reset(GlzEncDictContext *opaque_dict, GlzEncoderUsrContext *usr)
+{
+    Dict *d = (Dict *)opaque_dict;
+    std::lock_guard<std::recursive_mutex> lock(d->lock);
+    d->cur_usr = usr;
+    dict_reset(d);
+}
+
+void glz_enc_dictionary_remove_image(GlzEncDictContext *opaque_dict,
+                                     GlzEncDictImageContext *opaque_image,
+                                     GlzEncoderUsrContext *usr)
+{
+    Dict *d = (Dict *)opaque_dict;
+    HostImage *im = (HostImage *)opaque_image;
+    std::lock_guard<std::recursive_mutex> lock(d->lock);
+    d->cur_usr = usr;
+    if (im->alive) {
+        im->alive = false; /* glz_encoder_dictionary.c:142-145 */
+        mark_image_dirty(d, im);
+    }
+}
+
+GlzEncoderContext *glz_encoder_create(uint8_t id, GlzEncDictContext *dictionary,
+                                      GlzEncoderUsrContext *usr)
+{
+    /* glz_encoder.c:131-134 */
+    if (!usr || !usr->error || !usr->warn || !usr->info || !usr->malloc || !usr->free ||
+        !usr->more_space) {
+        return nullptr;
+    }
+    Dict *d = (Dict *)dictionary;
+    if (!d || id >= d->max_encoders) {
+        return nullptr;
+    }
+    Encoder *e = new Encoder();
+    e->usr = usr;
+    e->id = id;
+    e->dict = d;
+    return (GlzEncoderContext *)e;
+}
+
+void glz_encoder_destroy(GlzEncoderContext *opaque_encoder)
+{
+    Encoder *e = (Encoder *)opaque_encoder;
+    if (!e) {
+        return;
+    }
+    e->out.release();
+    e->bounce.release();
+    delete e;
+}
+
+size_t spice_gpu_glz_out_bound(LzImageType type, int width, int height)
+{
+    /* worst case per pixel: a count byte plus the longest reference (7 bytes)
+     * for every 2 pixels, or a literal; the alpha plane adds one more pass */
+    size_t px = (size_t)width * (size_t)height;
+    size_t per = type == LZ_IMAGE_TYPE_RGBA ? 9 : 5;
+    return GLZ_HEADER_BYTES + px * per + 64;
+}
+
+int glz_encode(GlzEncoderContext *opaque_encoder, LzImageType type, int width, int height,
+               int top_down, uint8_t *lines, unsigned int num_lines, int stride,
+               uint8_t *io_ptr, unsigned int num_io_bytes, GlzUsrImageContext *usr_context,
+               GlzEncDictImageContext **o_enc_dict_context)
+{
+    Encoder *enc = (Encoder *)opaque_encoder;
+    Dict *d = enc->dict;
+    uint64_t t0 = now_ns();
+    if (!ensure_init()) {
+        usr_error(enc->usr, "no usable GPU\n");
+        return 0;
+    }
+    const char *bad = validate(type, width, height, stride);
+    if (bad) {
+        usr_error(enc->usr, bad);
+        return 0;
+    }
+
+    /* glz_encoder_dictionary.c:497-525: first chunk as passed, the rest pulled */
+    std::vector<Chunk> chunks;
+    {
+        uint32_t row = 0;
+        uint8_t *cur = lines;
+        int n = (int)num_lines;
+        while (row < (uint32_t)height) {
+            if (n <= 0) {
+                n = enc->usr->more_lines ? enc->usr->more_lines(enc->usr, &cur) : 0;
+                if (n <= 0) {
+                    usr_error(enc->usr, "more lines failed\n");
+                    return 0;
+                }
+            }
+            chunks.push_back(Chunk{cur, (uint32_t)n});
+            row += (uint32_t)n;
+            n = 0;
+        }
+    }
+
+    std::lock_guard<std::recursive_mutex> dict_lock(d->lock);
+    std::lock_guard<std::mutex> dev_lock(device_mutex());
+
+    size_t bound = spice_gpu_glz_out_bound(type, width, height);
+    if (!enc->out.reserve(bound) || !enc->bounce.reserve(bound)) {
+        usr_error(enc->usr, "device output buffer allocation failed\n");
+        return 0;
+    }
+    std::vector<Prepared> jobs(1);
+    const char *err = prepare(enc, type, width, height, top_down, stride, chunks, usr_context,
+                              enc->out.ptr, (uint32_t)bound, &jobs[0]);
+    if (err) {
+        usr_error(enc->usr, err);
+        return 0;
+    }
+    if (o_enc_dict_context) {
+        *o_enc_dict_context = (GlzEncDictImageContext *)jobs[0].image;
+    }
+
+    hipStream_t s = stream();
+    static Staging staging;
+    size_t res_off = 0;
+    bool ok = true;
+    for (const GlzCopyDesc &c : jobs[0].copies) {
+        ok = ok && check(hipMemcpyAsync(c.dst, c.src, c.bytes, hipMemcpyHostToDevice, s), "upload rows");
+    }
+    ok = ok && launch(jobs, staging, &res_off, false);
+    ok = ok && check(hipStreamSynchronize(s), "glz sync");
+    int32_t size = ok ? *(int32_t *)(staging.host + res_off) : 0;
+    if (ok && size > 0) {
+        ok = check(hipMemcpyAsync(enc->bounce.ptr, enc->out.ptr, (size_t)size,
+                                  hipMemcpyDeviceToHost, s), "download stream") &&
+             check(hipStreamSynchronize(s), "glz sync");
+    }
+    post_encode(d, enc->id);
+    if (!ok || size <= 0) {
+        usr_error(enc->usr, ok ? "no more bytes\n" : "device failure\n");
+        return 0;
+    }
+
+    /* hand the stream out through io_ptr and then more_space (glz_encoder.c:52-73) */
+    {
+        size_t left = (size_t)size;
+        const uint8_t *src = enc->bounce.ptr;
+        uint8_t *dst = io_ptr;
+        size_t room = num_io_bytes;
+        while (left) {
+            if (room == 0) {
+                int got = enc->usr->more_space(enc->usr, &dst);
+                if (got <= 0) {
+                    usr_error(enc->usr, "no more bytes\n");
+                    return 0;
+                }
+                room = (size_t)got;
+            }
+            size_t n = left < room ? left : room;
+            memcpy(dst, src, n);
+            src += n;
+            dst += n;
+            left -= n;
+            room -= n;
+        }
+    }
+    stat_add(SPICE_GPU_STAT_GLZ, jobs[0].raw_bytes, (uint64_t)size, now_ns() - t0);
+    return size;
+}
+
+int spice_gpu_glz_submit(SpiceGpuGlzJob *jobs, int njobs)
+{
+    if (!ensure_init()) {
+        return -1;
+    }
+    if (njobs <= 0) {
+        set_error("glz batch: no jobs");
+        return -1;
+    }
+    Flight &f = g_flight;
+    /* lock order everywhere: dictionaries, then the device */
+    std::vector<std::unique_lock<std::recursive_mutex>> dict_locks;
+    for (int j = 0; j < njobs; j++) {
+        Encoder *enc = (Encoder *)jobs[j].encoder;
+        if (!enc) {
+            set_error("glz batch job %d: null encoder", j);
+            return -1;
+        }
+        for (int k = 0; k < j; k++) {
+            if (((Encoder *)jobs[k].encoder)->dict == enc->dict) {
+                set_error("glz batch job %d: two jobs of one batch share a dictionary", j);
+                return -1;
+            }
+        }
+        dict_locks.emplace_back(enc->dict->lock);
+    }
+    std::unique_lock<std::mutex> dev_lock(device_mutex());
+    if (f.active) {
+        set_error("glz batch: a batch is already in flight");
+        return -1;
+    }
+    f.jobs.clear();
+    f.jobs.resize((size_t)njobs);
+    f.dict_locks = std::move(dict_locks);
+    f.t0 = now_ns();
+
+    for (int j = 0; j < njobs; j++) {
+        SpiceGpuGlzJob &job = jobs[j];
+        Encoder *enc = (Encoder *)job.encoder;
+        job.out_size = -1;
+        job.dict_image = nullptr;
+        const char *err = validate(job.type, job.width, job.height, job.stride);
+        if (!err) {
+            std::vector<Chunk> chunks;
+            for (int c = 0; c < job.nchunks; c++) {
+                chunks.push_back(Chunk{(const uint8_t *)job.chunk_ptrs[c], job.chunk_rows[c]});
+            }
+            err = prepare(enc, job.type, job.width, job.height, job.top_down, job.stride, chunks,
+                          job.usr_context, (uint8_t *)job.out, job.out_capacity, &f.jobs[(size_t)j]);
+            if (!err) {
+                job.dict_image = (GlzEncDictImageContext *)f.jobs[(size_t)j].image;
+            }
+        }
+        if (err) {
+            /* jobs prepared so far have changed their windows; close them properly */
+            set_error("glz batch job %d: %s", j, err);
+            for (int k = 0; k < j; k++) {
+                Encoder *e = (Encoder *)jobs[k].encoder;
+                post_encode(e->dict, e->id);
+            }
+            f.dict_locks.clear();
+            f.jobs.clear();
+            return -1;
+        }
+    }
+    if (!launch(f.jobs, f.staging, &f.results_off, true)) {
+        for (int k = 0; k < njobs; k++) {
+            Encoder *e = (Encoder *)jobs[k].encoder;
+            post_encode(e->dict, e->id);
+        }
+        f.dict_locks.clear();
+        f.jobs.clear();
+        return -1;
+    }
+    f.active = true;
+    f.dev_lock = std::move(dev_lock);
+    return 0;
+}
+
+int spice_gpu_glz_finish(SpiceGpuGlzJob *jobs, int njobs)
+{
+    Flight &f = g_flight;
+    if (!f.active || (size_t)njobs != f.jobs.size()) {
+        set_error("glz batch: finish without a matching submit");
+        return -1;
+    }
+    bool ok = check(hipStreamSynchronize(stream()), "glz batch sync");
+    const int32_t *res = (const int32_t *)(f.staging.host + f.results_off);
+    int rc = ok ? 0 : -1;
+    uint64_t dt = now_ns() - f.t0;
+    for (int j = 0; j < njobs; j++) {
+        Encoder *e = (Encoder *)jobs[j].encoder;
+        jobs[j].out_size = ok ? res[j] : -1;
+        post_encode(e->dict, e->id);
+        if (jobs[j].out_size <= 0) {
+            if (ok) {
+                set_error("glz batch job %d: device error %d", j, jobs[j].out_size);
+            }
+            rc = -1;
+        } else {
+            stat_add(SPICE_GPU_STAT_GLZ, f.jobs[(size_t)j].raw_bytes, (uint64_t)jobs[j].out_size,
+                     dt / (uint64_t)njobs);
+        }
+    }
+    f.dict_locks.clear();
+    f.jobs.clear();
+    f.active = false;
+    f.dev_lock.unlock();
+    f.dev_lock = std::unique_lock<std::mutex>();
+    return rc;
+}
+
+int spice_gpu_glz_encode_batch(SpiceGpuGlzJob *jobs, int njobs)
+{
+    if (spice_gpu_glz_submit(jobs, njobs) != 0) {
+        return -1;
+    }
+    return spice_gpu_glz_finish(jobs, njobs);
+}
+
+} // extern "C"

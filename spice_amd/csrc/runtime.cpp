@@ -1,0 +1,272 @@
+/*
+ * Process-wide device state of libspicegpu (see runtime.h).
+ */
+#include "runtime.h"
+
+#include <stdio.h>
+#include <string.h>
+#include <time.h>
+
+namespace spicegpu {
+
+namespace {
+std::mutex g_init_mutex;
+std::mutex g_device_mutex;
+std::mutex g_stat_mutex;
+bool g_ready = false;
+int g_device = -1;
+hipStream_t g_stream = nullptr;
+thread_local char g_error[512] = "";
+SpiceGpuCodecStats g_stats[SPICE_GPU_STAT_COUNT];
+} // namespace
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof(g_error), fmt, ap);
+    va_end(ap);
+}
+
+bool check(hipError_t e, const char *what)
+{
+    if (e == hipSuccess) {
+        return true;
+    }
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return false;
+}
+
+static bool init_locked(int device)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        set_error("no HIP device visible: libspicegpu has no CPU fallback");
+        return false;
+    }
+    if (device < 0 || device >= count) {
+        set_error("device %d out of range (%d visible)", device, count);
+        return false;
+    }
+    if (!check(hipSetDevice(device), "hipSetDevice")) {
+        return false;
+    }
+    if (!g_stream && !check(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking),
+                            "hipStreamCreate")) {
+        return false;
+    }
+    g_device = device;
+    g_ready = true;
+    return true;
+}
+
+bool ensure_init()
+{
+    std::lock_guard<std::mutex> lock(g_init_mutex);
+    if (g_ready) {
+        /* worker threads other than the initialising one need the device bound */
+        return check(hipSetDevice(g_device), "hipSetDevice");
+    }
+    return init_locked(0);
+}
+
+hipStream_t stream()
+{
+    return g_stream;
+}
+
+std::mutex &device_mutex()
+{
+    return g_device_mutex;
+}
+
+uint64_t now_ns()
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+}
+
+void stat_add(int codec, uint64_t orig, uint64_t comp, uint64_t ns)
+{
+    std::lock_guard<std::mutex> lock(g_stat_mutex);
+    SpiceGpuCodecStats &s = g_stats[codec];
+    if (s.count == 0 || ns < s.min_ns) {
+        s.min_ns = ns;
+    }
+    if (ns > s.max_ns) {
+        s.max_ns = ns;
+    }
+    s.count++;
+    s.orig_bytes += orig;
+    s.comp_bytes += comp;
+    s.total_ns += ns;
+}
+
+bool Staging::reserve(size_t bytes)
+{
+    if (bytes <= cap) {
+        return true;
+    }
+    size_t ncap = cap ? cap : 4096;
+    while (ncap < bytes) {
+        ncap *= 2;
+    }
+    release();
+    if (!check(hipHostMalloc((void **)&host, ncap, hipHostMallocDefault), "hipHostMalloc") ||
+        !check(hipMalloc((void **)&dev, ncap), "hipMalloc")) {
+        release();
+        return false;
+    }
+    cap = ncap;
+    return true;
+}
+
+void Staging::release()
+{
+    if (host) {
+        hipHostFree(host);
+    }
+    if (dev) {
+        hipFree(dev);
+    }
+    host = dev = nullptr;
+    cap = 0;
+}
+
+bool DevBuffer::reserve(size_t bytes)
+{
+    if (bytes <= cap) {
+        return true;
+    }
+    size_t ncap = cap ? cap : 4096;
+    while (ncap < bytes) {
+        ncap *= 2;
+    }
+    release();
+    if (!check(hipMalloc((void **)&ptr, ncap), "hipMalloc")) {
+        ptr = nullptr;
+        return false;
+    }
+    cap = ncap;
+    return true;
+}
+
+void DevBuffer::release()
+{
+    if (ptr) {
+        hipFree(ptr);
+    }
+    ptr = nullptr;
+    cap = 0;
+}
+
+bool PinnedBuffer::reserve(size_t bytes)
+{
+    if (bytes <= cap) {
+        return true;
+    }
+    size_t ncap = cap ? cap : 4096;
+    while (ncap < bytes) {
+        ncap *= 2;
+    }
+    release();
+    if (!check(hipHostMalloc((void **)&ptr, ncap, hipHostMallocDefault), "hipHostMalloc")) {
+        ptr = nullptr;
+        return false;
+    }
+    cap = ncap;
+    return true;
+}
+
+void PinnedBuffer::release()
+{
+    if (ptr) {
+        hipHostFree(ptr);
+    }
+    ptr = nullptr;
+    cap = 0;
+}
+
+} // namespace spicegpu
+
+using namespace spicegpu;
+
+extern "C" {
+
+int spice_gpu_init(int device)
+{
+    std::lock_guard<std::mutex> lock(g_init_mutex);
+    return init_locked(device) ? 0 : -1;
+}
+
+void spice_gpu_shutdown(void)
+{
+    std::lock_guard<std::mutex> lock(g_init_mutex);
+    if (g_stream) {
+        hipStreamSynchronize(g_stream);
+        hipStreamDestroy(g_stream);
+        g_stream = nullptr;
+    }
+    g_ready = false;
+}
+
+const char *spice_gpu_last_error(void)
+{
+    return g_error;
+}
+
+void *spice_gpu_stream(void)
+{
+    return ensure_init() ? (void *)g_stream : nullptr;
+}
+
+void *spice_gpu_malloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (!ensure_init() || !check(hipMalloc(&p, bytes ? bytes : 1), "hipMalloc")) {
+        return nullptr;
+    }
+    return p;
+}
+
+void spice_gpu_free(void *dev_ptr)
+{
+    if (dev_ptr) {
+        hipFree(dev_ptr);
+    }
+}
+
+int spice_gpu_upload(void *dev_dst, const void *host_src, size_t bytes)
+{
+    if (!ensure_init()) {
+        return -1;
+    }
+    return check(hipMemcpy(dev_dst, host_src, bytes, hipMemcpyHostToDevice), "hipMemcpy H2D") ? 0 : -1;
+}
+
+int spice_gpu_download(void *host_dst, const void *dev_src, size_t bytes)
+{
+    if (!ensure_init()) {
+        return -1;
+    }
+    return check(hipMemcpy(host_dst, dev_src, bytes, hipMemcpyDeviceToHost), "hipMemcpy D2H") ? 0 : -1;
+}
+
+void spice_gpu_get_stats(int codec, SpiceGpuCodecStats *out)
+{
+    std::lock_guard<std::mutex> lock(g_stat_mutex);
+    if (codec >= 0 && codec < SPICE_GPU_STAT_COUNT) {
+        *out = g_stats[codec];
+    } else {
+        memset(out, 0, sizeof(*out));
+    }
+}
+
+void spice_gpu_reset_stats(void)
+{
+    std::lock_guard<std::mutex> lock(g_stat_mutex);
+    memset(g_stats, 0, sizeof(g_stats));
+}
+
+} // extern "C"

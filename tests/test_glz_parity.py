@@ -1,0 +1,139 @@
+"""GLZ: the HIP parse against the CPU oracle, byte for byte.
+
+The same cases run twice: through the CPU wave simulator build of the kernel
+sources (no GPU needed; guards every device buffer) and, marked gpu, through
+libspicegpu.so on the MI355X.  Both go through the C ABI (glz_encode with the
+reference's more_lines / more_space callbacks).
+"""
+import numpy as np
+import pytest
+
+from spice_amd import binding as B
+from spice_amd import frames
+
+from helpers import GlzPair, pixels_for, small_desktop, split_rows
+
+TYPES = [B.LZ_IMAGE_TYPE_RGB32, B.LZ_IMAGE_TYPE_RGBA, B.LZ_IMAGE_TYPE_RGB24, B.LZ_IMAGE_TYPE_RGB16]
+SIZES = [(64, 32), (100, 60), (7, 3), (1, 1), (3, 1), (200, 50), (2, 2), (130, 70), (6, 1), (7, 1)]
+
+
+def run_mixed_sequence(dev, oracle, typ, nimages, window=40000):
+    """Small window so that images are evicted; ragged sizes; 1..3 chunks;
+    one logical removal; both row orders."""
+    rng = np.random.default_rng(typ)
+    pair = GlzPair(dev, oracle, window)
+    try:
+        for i in range(nimages):
+            w, h = SIZES[i % len(SIZES)]
+            px = pixels_for(typ, small_desktop(w, h, i // 2), rng)
+            chunks = split_rows(px, 1 if i % 3 else 3)
+            _, oimg, gimg = pair.encode(typ, w, h, px.shape[1], chunks, top_down=bool(i % 2),
+                                        what="mixed", direct=(i % 4 == 1))
+            if i == 5:
+                pair.od.remove_image(oimg)
+                pair.gd.remove_image(gimg)
+    finally:
+        pair.close()
+
+
+def run_noise_and_runs(dev, oracle, typ):
+    """Incompressible noise (all literals), a constant image (one run), stripes
+    with period inside and outside the 64-position window."""
+    rng = np.random.default_rng(99)
+    pair = GlzPair(dev, oracle, 1 << 16)
+    try:
+        w, h = 96, 40
+        imgs = []
+        noise = np.zeros((h, w, 4), np.uint8)
+        noise[..., :3] = rng.integers(0, 256, (h, w, 3))
+        imgs.append(noise)
+        flat = np.zeros((h, w, 4), np.uint8)
+        flat[..., :3] = (9, 200, 77)
+        imgs.append(flat)
+        for period in (2, 3, 5, 31, 64, 65, 97, 200):
+            a = np.zeros((h * w, 4), np.uint8)
+            base = rng.integers(0, 256, (period, 3))
+            a[:, :3] = base[np.arange(h * w) % period]
+            imgs.append(a.reshape(h, w, 4))
+        imgs.append(noise)  # cross-image match of the whole frame
+        for k, im in enumerate(imgs):
+            px = pixels_for(typ, im, rng)
+            pair.encode(typ, w, h, px.shape[1], [px], what="pattern %d" % k)
+    finally:
+        pair.close()
+
+
+def run_desktop_frames(dev, oracle, w, h, nframes, window, nchunks=1):
+    seq = frames.DesktopSequence(w, h, seed=11)
+    rng = np.random.default_rng(0)
+    pair = GlzPair(dev, oracle, window)
+    try:
+        for k in range(nframes):
+            px = pixels_for(B.LZ_IMAGE_TYPE_RGB32, seq.next(), rng)
+            pair.encode(B.LZ_IMAGE_TYPE_RGB32, w, h, w * 4, split_rows(px, nchunks), what="desktop")
+    finally:
+        pair.close()
+
+
+def run_plumbing(dev, oracle):
+    """The reference harness's own update bitmaps on a 1024x768 primary
+    (server/tests/test_display_base.c:212-271)."""
+    pair = GlzPair(dev, oracle, 1 << 20)
+    try:
+        for t in range(6):
+            tile = frames.plumbing_tile(1024, t, color=t % 2, c_i=t // 2)
+            h, w = tile.shape[:2]
+            pair.encode(B.LZ_IMAGE_TYPE_RGB32, w, h, w * 4, [tile.reshape(h, -1)], what="plumbing tile")
+        solid = frames.plumbing_solid(320, 240, 0x00ff8040)
+        pair.encode(B.LZ_IMAGE_TYPE_RGB32, 320, 240, 320 * 4, [solid.reshape(240, -1)], what="solid")
+    finally:
+        pair.close()
+
+
+# ------------------------------------------------------------------ CPU (sim)
+@pytest.mark.parametrize("typ", TYPES)
+def test_sim_mixed_sequence(sim, oracle, typ):
+    run_mixed_sequence(sim, oracle, typ, 40)
+
+
+@pytest.mark.parametrize("typ", [B.LZ_IMAGE_TYPE_RGB32, B.LZ_IMAGE_TYPE_RGBA, B.LZ_IMAGE_TYPE_RGB16])
+def test_sim_noise_and_runs(sim, oracle, typ):
+    run_noise_and_runs(sim, oracle, typ)
+
+
+def test_sim_desktop_frames(sim, oracle):
+    run_desktop_frames(sim, oracle, 320, 200, 4, window=200000, nchunks=2)
+
+
+def test_sim_plumbing(sim, oracle):
+    run_plumbing(sim, oracle)
+
+
+# ------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("typ", TYPES)
+def test_gpu_mixed_sequence(gpu, oracle, typ):
+    run_mixed_sequence(gpu, oracle, typ, 60)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("typ", TYPES)
+def test_gpu_noise_and_runs(gpu, oracle, typ):
+    run_noise_and_runs(gpu, oracle, typ)
+
+
+@pytest.mark.gpu
+def test_gpu_desktop_frames_small(gpu, oracle):
+    run_desktop_frames(gpu, oracle, 640, 400, 6, window=1 << 20, nchunks=3)
+
+
+@pytest.mark.gpu
+def test_gpu_plumbing(gpu, oracle):
+    run_plumbing(gpu, oracle)
+
+
+@pytest.mark.gpu
+def test_gpu_desktop_1080p_window_16m(gpu, oracle):
+    """BASELINE configs[1]: 1920x1080 frames through a 16 Mi-pixel window; the
+    9th frame evicts the first."""
+    run_desktop_frames(gpu, oracle, 1920, 1080, 10, window=16 * 1024 * 1024)
