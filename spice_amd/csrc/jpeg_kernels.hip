@@ -1,0 +1,742 @@
+/*
+ * Baseline JPEG (YCbCr 4:2:0, standard tables) for gfx950, bit-exact with the
+ * libjpeg configuration the reference selects (server/mjpeg_encoder.c:771-823:
+ * JDCT_IFAST; server/jpeg_encoder.c:232-246: JDCT_ISLOW).
+ *
+ * jpeg_strip_kernel: one 256-lane workgroup per strip of up to 40 MCUs.
+ *   phase 1  coalesced pixel reads (RGB16 / BGR24 / BGRX32 converters of
+ *            server/mjpeg_encoder.c:236-259), libjpeg's fixed-point RGB->YCbCr,
+ *            2x2 chroma box filter with the alternating 1,2 bias, edge
+ *            replication exactly where libjpeg applies it; samples go to LDS
+ *   phase 2  one lane per 8x8 block: the whole integer DCT (LL&M "islow" or
+ *            AA&N "ifast") and the divide-with-rounding quantiser in registers
+ *   phase 3  Huffman: bit lengths -> workgroup scan -> each lane ORs its codes
+ *            into the strip's bit buffer in LDS at its own bit offset
+ * The DC predictor of the strip's first MCU comes from recomputing the MCU
+ * just before the strip (a one-MCU halo), so strips need no ordering.
+ *
+ * The three small kernels after it work on compressed bytes only: scan of
+ * strip bit counts, bit-granular concatenation, 0xFF byte stuffing.
+ */
+#include <hip/hip_runtime.h>
+
+#include "jpeg_device.h"
+
+#define JT JPEG_STRIP_THREADS
+#define JSLOTS (JPEG_STRIP_MCUS + 1)          /* slot 0 is the halo MCU */
+#define YT_STRIDE (JSLOTS * 16)               /* bytes per luma tile row */
+#define CT_STRIDE (JSLOTS * 8)
+#define JBITBUF_WORDS 5120                    /* 20 KiB of LDS for a strip's bits */
+
+/* zigzag position -> natural index */
+#define JZZ_LIST \
+    0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, \
+    13, 6, 7, 14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, \
+    52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63
+
+/* ---------------------------------------------------------------- pixels */
+/* r | g << 8 | b << 16 of source pixel (x, y); converters of mjpeg_encoder.c:236-259 */
+__device__ __forceinline__ uint32_t jpeg_fetch_rgb(const JpegDevJob &job, int x, int y)
+{
+    const uint8_t *row = job.pixels + (int64_t)y * job.stride;
+    if (job.format == 8 || job.format == 9) {
+        const uint32_t p = ((const uint32_t *)row)[x];
+        return ((p >> 16) & 0xff) | (p & 0xff00) | ((p & 0xff) << 16);
+    } else if (job.format == 7) {
+        const uint8_t *p = row + x * 3;
+        return (uint32_t)p[2] | ((uint32_t)p[1] << 8) | ((uint32_t)p[0] << 16);
+    } else if (job.format == JPEG_FMT_RGB24) {
+        /* already r,g,b: convert_RGB24_to_RGB24, server/jpeg_encoder.c:160-163 */
+        const uint8_t *p = row + x * 3;
+        return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+    } else {
+        const uint32_t p = ((const uint16_t *)row)[x];
+        const uint32_t r = ((p >> 7) & 0xf8) | ((p >> 12) & 0x7);
+        const uint32_t g = ((p >> 2) & 0xf8) | ((p >> 7) & 0x7);
+        const uint32_t b = ((p << 3) & 0xf8) | ((p >> 2) & 0x7);
+        return r | (g << 8) | (b << 16);
+    }
+}
+
+/* libjpeg jccolor.c, 16-bit fixed point */
+__device__ __forceinline__ int jpeg_y(uint32_t rgb)
+{
+    const int r = rgb & 0xff, g = (rgb >> 8) & 0xff, b = (rgb >> 16) & 0xff;
+    return (19595 * r + 38470 * g + 7471 * b + 32768) >> 16;
+}
+__device__ __forceinline__ int jpeg_cb(uint32_t rgb)
+{
+    const int r = rgb & 0xff, g = (rgb >> 8) & 0xff, b = (rgb >> 16) & 0xff;
+    return (-11059 * r - 21709 * g + 32768 * b + (128 << 16) + 32767) >> 16;
+}
+__device__ __forceinline__ int jpeg_cr(uint32_t rgb)
+{
+    const int r = rgb & 0xff, g = (rgb >> 8) & 0xff, b = (rgb >> 16) & 0xff;
+    return (32768 * r - 27439 * g - 5329 * b + (128 << 16) + 32767) >> 16;
+}
+
+/* ------------------------------------------------------------------- DCTs */
+#define JDESCALE(x, n) (((x) + (1 << ((n) - 1))) >> (n))
+
+/* libjpeg jfdctint.c, one 8-point pass; FIRST: row pass (scale up by 4) */
+template <bool FIRST>
+__device__ __forceinline__ void jpeg_islow_1d(int &d0, int &d1, int &d2, int &d3, int &d4, int &d5,
+                                              int &d6, int &d7)
+{
+    const int sh = FIRST ? 11 : 15;
+    int t0 = d0 + d7, t7 = d0 - d7, t1 = d1 + d6, t6 = d1 - d6;
+    int t2 = d2 + d5, t5 = d2 - d5, t3 = d3 + d4, t4 = d3 - d4;
+    const int t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
+    if (FIRST) {
+        d0 = (t10 + t11) << 2;
+        d4 = (t10 - t11) << 2;
+    } else {
+        d0 = JDESCALE(t10 + t11, 2);
+        d4 = JDESCALE(t10 - t11, 2);
+    }
+    int z1 = (t12 + t13) * 4433;
+    d2 = JDESCALE(z1 + t13 * 6270, sh);
+    d6 = JDESCALE(z1 + t12 * (-15137), sh);
+    z1 = t4 + t7;
+    int z2 = t5 + t6, z3 = t4 + t6, z4 = t5 + t7;
+    const int z5 = (z3 + z4) * 9633;
+    t4 *= 2446;
+    t5 *= 16819;
+    t6 *= 25172;
+    t7 *= 12299;
+    z1 *= -7373;
+    z2 *= -20995;
+    z3 = z3 * (-16069) + z5;
+    z4 = z4 * (-3196) + z5;
+    d7 = JDESCALE(t4 + z1 + z3, sh);
+    d5 = JDESCALE(t5 + z2 + z4, sh);
+    d3 = JDESCALE(t6 + z2 + z3, sh);
+    d1 = JDESCALE(t7 + z1 + z4, sh);
+}
+
+/* libjpeg jfdctfst.c, one 8-point pass (products truncated by >> 8) */
+__device__ __forceinline__ void jpeg_ifast_1d(int &d0, int &d1, int &d2, int &d3, int &d4, int &d5,
+                                              int &d6, int &d7)
+{
+    const int t0 = d0 + d7, t7 = d0 - d7, t1 = d1 + d6, t6 = d1 - d6;
+    const int t2 = d2 + d5, t5 = d2 - d5, t3 = d3 + d4, t4 = d3 - d4;
+    int t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
+    d0 = t10 + t11;
+    d4 = t10 - t11;
+    const int z1 = ((t12 + t13) * 181) >> 8;
+    d2 = t13 + z1;
+    d6 = t13 - z1;
+    t10 = t4 + t5;
+    t11 = t5 + t6;
+    t12 = t6 + t7;
+    const int z5 = ((t10 - t12) * 98) >> 8;
+    const int z2 = ((t10 * 139) >> 8) + z5;
+    const int z4 = ((t12 * 334) >> 8) + z5;
+    const int z3 = (t11 * 181) >> 8;
+    const int z11 = t7 + z3, z13 = t7 - z3;
+    d5 = z13 + z2;
+    d3 = z13 - z2;
+    d1 = z11 + z4;
+    d7 = z11 - z4;
+}
+
+#define J8(a, o, s) a[o], a[o + s], a[o + 2 * s], a[o + 3 * s], a[o + 4 * s], a[o + 5 * s], a[o + 6 * s], a[o + 7 * s]
+
+template <bool IFAST>
+__device__ __forceinline__ void jpeg_fdct(int (&c)[64])
+{
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        if (IFAST) {
+            jpeg_ifast_1d(J8(c, r * 8, 1));
+        } else {
+            jpeg_islow_1d<true>(J8(c, r * 8, 1));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if (IFAST) {
+            jpeg_ifast_1d(J8(c, k, 8));
+        } else {
+            jpeg_islow_1d<false>(J8(c, k, 8));
+        }
+    }
+}
+
+/* libjpeg jcdctmgr.c forward_DCT: round-to-nearest division by the divisor */
+__device__ __forceinline__ int jpeg_quant(int v, int d, float rcp)
+{
+    const unsigned a = (unsigned)(v < 0 ? -v : v) + ((unsigned)d >> 1);
+    unsigned q = (unsigned)((float)a * rcp);
+    int rem = (int)(a - q * (unsigned)d);
+    if (rem < 0) {
+        q--;
+        rem += d;
+    }
+    if (rem >= d) {
+        q++;
+    }
+    return v < 0 ? -(int)q : (int)q;
+}
+
+/* ---------------------------------------------------------------- Huffman */
+/* packed table entry: size << 16 | code */
+struct JpegBitWriter {
+    uint32_t *words;
+    uint32_t widx;
+    uint64_t acc;
+    int n;
+    bool first;
+};
+
+__device__ __forceinline__ void jpeg_bw_init(JpegBitWriter &w, uint32_t *words, uint32_t bitpos)
+{
+    w.words = words;
+    w.widx = bitpos >> 5;
+    w.n = (int)(bitpos & 31);
+    w.acc = 0;
+    w.first = true;
+}
+
+__device__ __forceinline__ void jpeg_bw_put(JpegBitWriter &w, uint32_t code, int size)
+{
+    w.acc = (w.acc << size) | (uint64_t)(code & ((1u << size) - 1));
+    w.n += size;
+    if (w.n >= 32) {
+        const uint32_t v = (uint32_t)(w.acc >> (w.n - 32));
+        if (w.first) {
+            atomicOr(&w.words[w.widx], v); /* shared with the previous block's tail */
+            w.first = false;
+        } else {
+            w.words[w.widx] = v;
+        }
+        w.widx++;
+        w.n -= 32;
+        w.acc &= (1ull << w.n) - 1;
+    }
+}
+
+__device__ __forceinline__ void jpeg_bw_finish(JpegBitWriter &w)
+{
+    if (w.n > 0) {
+        atomicOr(&w.words[w.widx], (uint32_t)(w.acc << (32 - w.n)));
+    }
+}
+
+__device__ __forceinline__ int jpeg_nbits(int a)
+{
+    return 32 - __clz(a);
+}
+
+/* libjpeg jchuff.c encode_one_block.  EMIT=false only adds up the bits. */
+template <bool EMIT>
+__device__ __forceinline__ int jpeg_huff_block(const int (&c)[64], int diff, const uint32_t *dc_tab,
+                                               const uint32_t *ac_tab, JpegBitWriter &w)
+{
+    constexpr int zz[64] = {JZZ_LIST};
+    int bits = 0;
+    {
+        int t = diff, t2 = diff;
+        if (t < 0) {
+            t = -t;
+            t2--;
+        }
+        const int nb = t ? jpeg_nbits(t) : 0;
+        const uint32_t e = dc_tab[nb];
+        bits += (int)(e >> 16) + nb;
+        if (EMIT) {
+            jpeg_bw_put(w, e & 0xffff, (int)(e >> 16));
+            if (nb) {
+                jpeg_bw_put(w, (uint32_t)t2, nb);
+            }
+        }
+    }
+    int r = 0;
+#pragma unroll
+    for (int k = 1; k < 64; k++) {
+        int t = c[zz[k]];
+        if (t == 0) {
+            r++;
+        } else {
+            while (r > 15) {
+                const uint32_t z = ac_tab[0xf0];
+                bits += (int)(z >> 16);
+                if (EMIT) {
+                    jpeg_bw_put(w, z & 0xffff, (int)(z >> 16));
+                }
+                r -= 16;
+            }
+            int t2 = t;
+            if (t < 0) {
+                t = -t;
+                t2--;
+            }
+            const int nb = jpeg_nbits(t);
+            const uint32_t e = ac_tab[(r << 4) + nb];
+            bits += (int)(e >> 16) + nb;
+            if (EMIT) {
+                jpeg_bw_put(w, e & 0xffff, (int)(e >> 16));
+                jpeg_bw_put(w, (uint32_t)t2, nb);
+            }
+            r = 0;
+        }
+    }
+    if (r > 0) {
+        const uint32_t e = ac_tab[0];
+        bits += (int)(e >> 16);
+        if (EMIT) {
+            jpeg_bw_put(w, e & 0xffff, (int)(e >> 16));
+        }
+    }
+    return bits;
+}
+
+/* Exclusive scan of one int per lane over the workgroup; *total gets the sum. */
+__device__ __forceinline__ int jpeg_block_scan(int v, int *wave_sums, int tid, int *total)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d);
+        if (lane >= d) {
+            inc += o;
+        }
+    }
+    if (lane == 63) {
+        wave_sums[wave] = inc;
+    }
+    __syncthreads();
+    int base = 0, sum = 0;
+    for (int k = 0; k < JT / 64; k++) {
+        const int s = wave_sums[k];
+        if (k < wave) {
+            base += s;
+        }
+        sum += s;
+    }
+    __syncthreads();
+    *total = sum;
+    return base + inc - v;
+}
+
+/* huff: [0..255] AC luma, [256..511] AC chroma, [512..527] DC luma, [528..543] DC chroma */
+#define JHUFF_WORDS 544
+
+template <bool IFAST>
+__device__ void jpeg_strip_body(const JpegDevJob &job, const uint32_t *huff_g, int strip)
+{
+    __shared__ __align__(16) uint8_t ytile[16 * YT_STRIDE];
+    __shared__ __align__(16) uint8_t cbtile[8 * CT_STRIDE];
+    __shared__ __align__(16) uint8_t crtile[8 * CT_STRIDE];
+    __shared__ int dcq[JSLOTS * 6];
+    __shared__ int lens[JT];
+    __shared__ int wave_sums[JT / 64];
+    __shared__ uint32_t huff[JHUFF_WORDS];
+    __shared__ uint32_t bitbuf[JBITBUF_WORDS];
+
+    const int tid = (int)threadIdx.x;
+    const int my = strip / job.strips_per_row;
+    const int mx0 = (strip % job.strips_per_row) * JPEG_STRIP_MCUS;
+    const int nm = min(JPEG_STRIP_MCUS, job.mcu_cols - mx0);
+    const bool has_halo = strip != 0;
+    const int ns = nm + 1;
+    /* the MCU coded just before this strip */
+    const int hlin = my * job.mcu_cols + mx0 - 1;
+    const int hy = has_halo ? hlin / job.mcu_cols : 0, hx = has_halo ? hlin % job.mcu_cols : 0;
+    const int W = job.width, H = job.height;
+    const int ch = (H + 1) >> 1; /* real downsampled rows */
+
+    for (int i = tid; i < JHUFF_WORDS; i += JT) {
+        huff[i] = huff_g[i];
+    }
+
+    /* ---- phase 1: 2x2 pixel quads -> 4 luma samples + 1 Cb + 1 Cr */
+    const int quads_x = ns * 8;
+    for (int item = tid; item < quads_x * 8; item += JT) {
+        const int qy = item / quads_x, qxs = item - qy * quads_x;
+        const int slot = qxs >> 3, qx = qxs & 7;
+        if (slot == 0 && !has_halo) {
+            continue;
+        }
+        const int mcx = slot == 0 ? hx : mx0 + slot - 1;
+        const int mcy = slot == 0 ? hy : my;
+        const int x = mcx * 16 + qx * 2, y = mcy * 16 + qy * 2;
+        /* chroma: rows are replicated after downsampling (jcprepct.c), columns before (jcsample.c) */
+        const int cyc = min(mcy * 8 + qy, ch - 1);
+        const int r0 = min(2 * cyc, H - 1), r1 = min(2 * cyc + 1, H - 1);
+        const int c0 = min(x, W - 1), c1 = min(x + 1, W - 1);
+        const uint32_t p00 = jpeg_fetch_rgb(job, c0, r0), p01 = jpeg_fetch_rgb(job, c1, r0);
+        const uint32_t p10 = jpeg_fetch_rgb(job, c0, r1), p11 = jpeg_fetch_rgb(job, c1, r1);
+        const int bias = (qx & 1) ? 2 : 1; /* chroma column parity within the MCU == global parity */
+        const int cb = (jpeg_cb(p00) + jpeg_cb(p01) + jpeg_cb(p10) + jpeg_cb(p11) + bias) >> 2;
+        const int cr = (jpeg_cr(p00) + jpeg_cr(p01) + jpeg_cr(p10) + jpeg_cr(p11) + bias) >> 2;
+        cbtile[qy * CT_STRIDE + slot * 8 + qx] = (uint8_t)cb;
+        crtile[qy * CT_STRIDE + slot * 8 + qx] = (uint8_t)cr;
+        /* luma: plain clamping of both coordinates */
+        uint32_t q00 = p00, q01 = p01, q10 = p10, q11 = p11;
+        if (y + 1 >= H) {
+            const int y0 = min(y, H - 1), y1 = min(y + 1, H - 1);
+            q00 = jpeg_fetch_rgb(job, c0, y0);
+            q01 = jpeg_fetch_rgb(job, c1, y0);
+            q10 = jpeg_fetch_rgb(job, c0, y1);
+            q11 = jpeg_fetch_rgb(job, c1, y1);
+        }
+        uint8_t *yp = &ytile[(qy * 2) * YT_STRIDE + slot * 16 + qx * 2];
+        yp[0] = (uint8_t)jpeg_y(q00);
+        yp[1] = (uint8_t)jpeg_y(q01);
+        yp[YT_STRIDE] = (uint8_t)jpeg_y(q10);
+        yp[YT_STRIDE + 1] = (uint8_t)jpeg_y(q11);
+    }
+    __syncthreads();
+
+    /* ---- phase 2: one lane per block.  Luma lanes are ordered so that a wave
+     * reads consecutive 8-byte columns of one tile row. */
+    int c[64];
+    int slot = 0, bidx = 0; /* block's MCU slot and its index 0..5 inside the MCU */
+    bool have = false, real = false;
+    if (tid < 4 * ns) {
+        const int yi = tid / (2 * ns), col = tid - yi * 2 * ns;
+        slot = col >> 1;
+        const int xi = col & 1;
+        bidx = yi * 2 + xi;
+        have = true;
+        const int mcx = slot == 0 ? hx : mx0 + slot - 1, mcy = slot == 0 ? hy : my;
+        real = (mcy * 2 + yi) < job.yb_h && (mcx * 2 + xi) < job.yb_w;
+        if (real) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const uint2 v = *(const uint2 *)&ytile[(yi * 8 + r) * YT_STRIDE + col * 8];
+                c[r * 8 + 0] = (int)(v.x & 0xff) - 128;
+                c[r * 8 + 1] = (int)((v.x >> 8) & 0xff) - 128;
+                c[r * 8 + 2] = (int)((v.x >> 16) & 0xff) - 128;
+                c[r * 8 + 3] = (int)(v.x >> 24) - 128;
+                c[r * 8 + 4] = (int)(v.y & 0xff) - 128;
+                c[r * 8 + 5] = (int)((v.y >> 8) & 0xff) - 128;
+                c[r * 8 + 6] = (int)((v.y >> 16) & 0xff) - 128;
+                c[r * 8 + 7] = (int)(v.y >> 24) - 128;
+            }
+        }
+    } else if (tid < 6 * ns) {
+        const int k = tid - 4 * ns;
+        const bool is_cr = k >= ns;
+        slot = is_cr ? k - ns : k;
+        bidx = is_cr ? 5 : 4;
+        have = true;
+        real = true;
+        const uint8_t *tile = is_cr ? crtile : cbtile;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint2 v = *(const uint2 *)&tile[r * CT_STRIDE + slot * 8];
+            c[r * 8 + 0] = (int)(v.x & 0xff) - 128;
+            c[r * 8 + 1] = (int)((v.x >> 8) & 0xff) - 128;
+            c[r * 8 + 2] = (int)((v.x >> 16) & 0xff) - 128;
+            c[r * 8 + 3] = (int)(v.x >> 24) - 128;
+            c[r * 8 + 4] = (int)(v.y & 0xff) - 128;
+            c[r * 8 + 5] = (int)((v.y >> 8) & 0xff) - 128;
+            c[r * 8 + 6] = (int)((v.y >> 16) & 0xff) - 128;
+            c[r * 8 + 7] = (int)(v.y >> 24) - 128;
+        }
+    }
+    if (slot == 0 && !has_halo) {
+        have = false;
+    }
+    if (have && real) {
+        jpeg_fdct<IFAST>(c);
+        const int *dv = bidx < 4 ? job.div_y : job.div_c;
+        const float *rc = bidx < 4 ? job.rcp_y : job.rcp_c;
+#pragma unroll
+        for (int i = 0; i < 64; i++) {
+            c[i] = jpeg_quant(c[i], dv[i], rc[i]);
+        }
+        dcq[slot * 6 + bidx] = c[0];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 64; i++) {
+            c[i] = 0;
+        }
+    }
+    __syncthreads();
+    /* dummy edge blocks repeat the DC of the block coded before them (jccoefct.c) */
+    if (tid < ns && (tid > 0 || has_halo)) {
+        const int mcx = tid == 0 ? hx : mx0 + tid - 1, mcy = tid == 0 ? hy : my;
+        for (int b = 1; b < 4; b++) {
+            const bool rl = (mcy * 2 + (b >> 1)) < job.yb_h && (mcx * 2 + (b & 1)) < job.yb_w;
+            if (!rl) {
+                dcq[tid * 6 + b] = dcq[tid * 6 + b - 1];
+            }
+        }
+    }
+    __syncthreads();
+
+    /* ---- phase 3: Huffman */
+    const bool coded = have && slot > 0;
+    int diff = 0;
+    if (coded) {
+        const int dc = dcq[slot * 6 + bidx];
+        int pred;
+        if (bidx == 0) {
+            pred = (slot == 1 && !has_halo) ? 0 : dcq[(slot - 1) * 6 + 3];
+        } else if (bidx < 4) {
+            pred = dcq[slot * 6 + bidx - 1];
+        } else {
+            pred = (slot == 1 && !has_halo) ? 0 : dcq[(slot - 1) * 6 + bidx];
+        }
+        diff = dc - pred;
+        if (!real) {
+            c[0] = dc; /* not used by the coder, kept for clarity */
+        }
+    }
+    const uint32_t *ac_tab = huff + (bidx < 4 ? 0 : 256);
+    const uint32_t *dc_tab = huff + (bidx < 4 ? 512 : 528);
+    JpegBitWriter bw;
+    bw.words = nullptr;
+    int mybits = 0;
+    if (coded) {
+        mybits = jpeg_huff_block<false>(c, diff, dc_tab, ac_tab, bw);
+        lens[(slot - 1) * 6 + bidx] = mybits;
+    }
+    for (int i = tid; i < JBITBUF_WORDS; i += JT) {
+        bitbuf[i] = 0;
+    }
+    __syncthreads();
+    int total = 0;
+    const int mine = tid < nm * 6 ? lens[tid] : 0;
+    const int excl = jpeg_block_scan(mine, wave_sums, tid, &total);
+    if (tid < nm * 6) {
+        lens[tid] = excl; /* now the bit offset of block tid (MCU order) */
+    }
+    __syncthreads();
+
+    uint32_t *slot_words = (uint32_t *)(job.strip_buf + (size_t)strip * job.strip_stride);
+    const int nwords = (total + 31) >> 5;
+    const bool in_lds = nwords <= JBITBUF_WORDS;
+    uint32_t *words = in_lds ? bitbuf : slot_words;
+    if (!in_lds) {
+        for (int i = tid; i < nwords; i += JT) {
+            slot_words[i] = 0;
+        }
+        __syncthreads();
+    }
+    if (coded) {
+        jpeg_bw_init(bw, words, (uint32_t)lens[(slot - 1) * 6 + bidx]);
+        jpeg_huff_block<true>(c, diff, dc_tab, ac_tab, bw);
+        jpeg_bw_finish(bw);
+    }
+    __syncthreads();
+    /* words hold the stream MSB first; memory order wants the bytes swapped */
+    for (int i = tid; i < nwords; i += JT) {
+        const uint32_t v = words[i];
+        slot_words[i] = (v >> 24) | ((v >> 8) & 0xff00) | ((v << 8) & 0xff0000) | (v << 24);
+    }
+    if (tid == 0) {
+        job.strip_bits[strip] = (uint32_t)total;
+    }
+}
+
+template <bool IFAST>
+__global__ void __launch_bounds__(JT)
+jpeg_strip_kernel(const JpegDevJob *jobs, const uint32_t *huff)
+{
+    const JpegDevJob &job = jobs[blockIdx.y];
+    const int strip = (int)blockIdx.x;
+    if (strip >= job.nstrips || (job.dct != 0) != IFAST) {
+        return;
+    }
+    jpeg_strip_body<IFAST>(job, huff, strip);
+}
+
+/* Exclusive scan of strip_bits into strip_bitoff (64-bit), one workgroup per job. */
+__global__ void __launch_bounds__(JT)
+jpeg_offsets_kernel(const JpegDevJob *jobs)
+{
+    __shared__ int wave_sums[JT / 64];
+    const JpegDevJob &job = jobs[blockIdx.x];
+    const int tid = (int)threadIdx.x;
+    uint64_t carry = 0;
+    for (int base = 0; base < job.nstrips; base += JT) {
+        const int i = base + tid;
+        const int v = i < job.nstrips ? (int)job.strip_bits[i] : 0;
+        int total = 0;
+        const int excl = jpeg_block_scan(v, wave_sums, tid, &total);
+        if (i < job.nstrips) {
+            job.strip_bitoff[i] = carry + (uint64_t)excl;
+        }
+        carry += (uint64_t)total;
+    }
+    if (tid == 0) {
+        job.strip_bitoff[job.nstrips] = carry;
+    }
+}
+
+/* Unstuffed scan: byte j holds stream bits [8j, 8j+8); the tail is padded with
+ * one-bits (jchuff.c flush_bits).  16 bytes per lane, 4 KiB per workgroup pass. */
+__global__ void __launch_bounds__(JT)
+jpeg_gather_kernel(const JpegDevJob *jobs)
+{
+    __shared__ int wave_sums[JT / 64];
+    const JpegDevJob &job = jobs[blockIdx.y];
+    const int tid = (int)threadIdx.x;
+    const uint64_t tbits = job.strip_bitoff[job.nstrips];
+    const uint64_t nbytes = (tbits + 7) >> 3;
+    const uint64_t usable = nbytes < job.scan_cap ? nbytes : job.scan_cap;
+    const uint32_t nchunks = (uint32_t)((usable + JPEG_CHUNK_BYTES - 1) / JPEG_CHUNK_BYTES);
+
+    for (uint32_t chunk = blockIdx.x; chunk < nchunks && chunk < job.nchunks_cap; chunk += gridDim.x) {
+        const uint64_t j0 = (uint64_t)chunk * JPEG_CHUNK_BYTES + (uint64_t)tid * 16;
+        int ff = 0;
+        if (j0 < usable) {
+            uint64_t bit = j0 * 8;
+            /* last strip whose offset is <= bit */
+            int lo = 0, hi = job.nstrips - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (job.strip_bitoff[mid] <= bit) {
+                    lo = mid;
+                } else {
+                    hi = mid - 1;
+                }
+            }
+            int s = lo;
+            uint64_t soff = job.strip_bitoff[s];
+            uint32_t sbits = job.strip_bits[s];
+            const uint8_t *sp = job.strip_buf + (size_t)s * job.strip_stride;
+            uint32_t out4[4] = {0, 0, 0, 0};
+            for (int k = 0; k < 16; k++) {
+                uint32_t byte = 0;
+                int got = 0;
+                if (j0 + (uint64_t)k < nbytes) {
+                    while (got < 8) {
+                        if (bit >= tbits) {
+                            byte |= (1u << (8 - got)) - 1; /* pad with ones */
+                            got = 8;
+                            break;
+                        }
+                        while (bit >= soff + sbits) {
+                            s++;
+                            soff = job.strip_bitoff[s];
+                            sbits = job.strip_bits[s];
+                            sp = job.strip_buf + (size_t)s * job.strip_stride;
+                        }
+                        const uint32_t local = (uint32_t)(bit - soff);
+                        const int avail = (int)(sbits - local);
+                        const int take = min(8 - got, avail);
+                        const uint32_t o = local >> 3, sh = local & 7;
+                        const uint32_t two = ((uint32_t)sp[o] << 8) | (uint32_t)sp[o + 1];
+                        const uint32_t bits8 = (two >> (8 - sh)) & 0xff; /* 8 bits from `local` */
+                        byte |= (bits8 >> (8 - take)) << (8 - got - take);
+                        got += take;
+                        bit += (uint64_t)take;
+                    }
+                    if (byte == 0xff) {
+                        ff++;
+                    }
+                }
+                out4[k >> 2] |= byte << (8 * (k & 3));
+            }
+            *(uint4 *)(job.scan_buf + j0) = make_uint4(out4[0], out4[1], out4[2], out4[3]);
+        }
+        int total = 0;
+        jpeg_block_scan(ff, wave_sums, tid, &total);
+        if (tid == 0) {
+            job.chunk_ff[chunk] = (uint32_t)total;
+        }
+    }
+}
+
+/* Header, byte-stuffed scan (a zero after every 0xFF), EOI, result. */
+__global__ void __launch_bounds__(JT)
+jpeg_finish_kernel(const JpegDevJob *jobs)
+{
+    __shared__ int wave_sums[JT / 64];
+    const JpegDevJob &job = jobs[blockIdx.y];
+    const int tid = (int)threadIdx.x;
+    const uint64_t tbits = job.strip_bitoff[job.nstrips];
+    const uint64_t nbytes = (tbits + 7) >> 3;
+    const bool fits_scan = nbytes <= job.scan_cap;
+    const uint32_t nchunks = (uint32_t)((nbytes + JPEG_CHUNK_BYTES - 1) / JPEG_CHUNK_BYTES);
+    const bool ok = fits_scan && nchunks <= job.nchunks_cap;
+
+    if (blockIdx.x == 0) {
+        for (uint32_t i = (uint32_t)tid; i < job.hdr_len && i < job.out_cap; i += JT) {
+            job.out[i] = job.header[i];
+        }
+        int part = 0;
+        if (ok) {
+            for (uint32_t i = (uint32_t)tid; i < nchunks; i += JT) {
+                part += (int)job.chunk_ff[i];
+            }
+        }
+        int total_ff = 0;
+        jpeg_block_scan(part, wave_sums, tid, &total_ff);
+        if (tid == 0) {
+            const uint64_t size = (uint64_t)job.hdr_len + nbytes + (uint64_t)total_ff + 2;
+            if (!ok || size > job.out_cap) {
+                *job.result = JPEG_DEV_ERR_NO_SPACE;
+            } else {
+                job.out[size - 2] = 0xff;
+                job.out[size - 1] = 0xd9;
+                *job.result = (int32_t)size;
+            }
+        }
+    }
+    if (!ok) {
+        return;
+    }
+    for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        int part = 0;
+        for (uint32_t i = (uint32_t)tid; i < chunk; i += JT) {
+            part += (int)job.chunk_ff[i];
+        }
+        int ff_before = 0;
+        jpeg_block_scan(part, wave_sums, tid, &ff_before);
+
+        const uint64_t j0 = (uint64_t)chunk * JPEG_CHUNK_BYTES + (uint64_t)tid * 16;
+        uint32_t w4[4] = {0, 0, 0, 0};
+        int ff = 0, n = 0;
+        if (j0 < nbytes) {
+            const uint4 v = *(const uint4 *)(job.scan_buf + j0);
+            w4[0] = v.x;
+            w4[1] = v.y;
+            w4[2] = v.z;
+            w4[3] = v.w;
+            n = (int)(nbytes - j0 < 16 ? nbytes - j0 : 16);
+            for (int k = 0; k < n; k++) {
+                if (((w4[k >> 2] >> (8 * (k & 3))) & 0xff) == 0xff) {
+                    ff++;
+                }
+            }
+        }
+        int dummy = 0;
+        const int ff_lane = jpeg_block_scan(ff, wave_sums, tid, &dummy);
+        uint64_t pos = (uint64_t)job.hdr_len + j0 + (uint64_t)ff_before + (uint64_t)ff_lane;
+        for (int k = 0; k < n; k++) {
+            const uint32_t b = (w4[k >> 2] >> (8 * (k & 3))) & 0xff;
+            if (pos < job.out_cap) {
+                job.out[pos] = (uint8_t)b;
+            }
+            pos++;
+            if (b == 0xff) {
+                if (pos < job.out_cap) {
+                    job.out[pos] = 0;
+                }
+                pos++;
+            }
+        }
+    }
+}
+
+void jpeg_launch(const JpegDevJob *jobs, int njobs, int max_strips, bool any_islow, bool any_ifast,
+                 const uint32_t *huff, hipStream_t stream)
+{
+    const dim3 grid((unsigned)max_strips, (unsigned)njobs);
+    if (any_islow) {
+        hipLaunchKernelGGL(jpeg_strip_kernel<false>, grid, dim3(JT), 0, stream, jobs, huff);
+    }
+    if (any_ifast) {
+        hipLaunchKernelGGL(jpeg_strip_kernel<true>, grid, dim3(JT), 0, stream, jobs, huff);
+    }
+    hipLaunchKernelGGL(jpeg_offsets_kernel, dim3((unsigned)njobs), dim3(JT), 0, stream, jobs);
+    hipLaunchKernelGGL(jpeg_gather_kernel, dim3(64, (unsigned)njobs), dim3(JT), 0, stream, jobs);
+    hipLaunchKernelGGL(jpeg_finish_kernel, dim3(64, (unsigned)njobs), dim3(JT), 0, stream, jobs);
+}

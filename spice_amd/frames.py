@@ -158,3 +158,31 @@ def to_rgb16(bgrx, rng=None):
 
 def to_bgr24(bgrx):
     return np.ascontiguousarray(bgrx[..., :3]).reshape(bgrx.shape[0], -1)
+
+
+def hash_noise(n, seed):
+    """n deterministic pseudo-random bytes (splitmix64 of the index); independent
+    of any library's generator so that committed golden vectors stay valid."""
+    with np.errstate(over="ignore"):
+        z = (np.arange(n, dtype=np.uint64) + np.uint64(seed) * np.uint64(0x9E3779B97F4A7C15))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (z & np.uint64(0xff)).astype(np.uint8)
+
+
+def golden_image(width, height, kind, seed):
+    """BGRX test images used by the committed golden vectors."""
+    if kind == "noise":
+        a = hash_noise(width * height * 4, seed).reshape(height, width, 4).copy()
+    elif kind == "smooth":
+        y, x = np.mgrid[0:height, 0:width]
+        a = np.stack([(x * 3 + y + seed) % 256, (x + y * 2) % 256, (x * y // 7) % 256,
+                      np.zeros_like(x)], -1).astype(np.uint8)
+        a[..., :3] ^= (hash_noise(width * height * 3, seed).reshape(height, width, 3) & 3)
+    elif kind == "desktop":
+        a = DesktopSequence(max(width, 96), max(height, 96), seed).next()[:height, :width].copy()
+    else:
+        raise ValueError(kind)
+    a[..., 3] = 0
+    return a

@@ -1,0 +1,159 @@
+"""MJPEG / still JPEG: the HIP kernels against libjpeg's own output (the golden
+vectors) and against the CPU oracle, byte for byte, through the C ABI."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from spice_amd import binding as B
+from spice_amd import frames
+
+from helpers import assert_same_stream, split_rows
+from test_oracle_pinning import case_pixels, jpeg_cases
+
+
+def batch_encode(dev, items):
+    """items: (pixels2d, w, h, fmt, q, dct, stride_sign) -> list of JFIF byte arrays."""
+    jobs, bufs = [], []
+    for (px, w, h, fmt, q, dct, sign) in items:
+        px = np.ascontiguousarray(px)
+        stride = px.shape[1]
+        d_px = dev.to_device(px)
+        cap = max(4096, w * h * 4 + 2048)
+        d_out = dev.malloc(cap)
+        first = d_px if sign > 0 else d_px + (h - 1) * stride
+        jobs.append(dict(pixels=first, format=fmt, width=w, height=h, stride=sign * stride,
+                         quality=q, dct=dct, out=d_out, out_capacity=cap))
+        bufs.append((d_px, d_out))
+    sizes = B.jpeg_encode_batch(dev, jobs)
+    outs = [dev.download(b[1], n) for b, n in zip(bufs, sizes)]
+    for d_px, d_out in bufs:
+        dev.free(d_px)
+        dev.free(d_out)
+    return outs
+
+
+def run_golden(dev, oracle, max_pixels, min_pixels=0, chunk=24):
+    cases = [c for c in jpeg_cases(max_pixels) if c["w"] * c["h"] >= min_pixels]
+    assert cases
+    for i in range(0, len(cases), chunk):
+        part = cases[i:i + chunk]
+        items = [(case_pixels(oracle, c), c["w"], c["h"], c["fmt"], c["q"], c["dct"], 1) for c in part]
+        for c, got in zip(part, batch_encode(dev, items)):
+            assert len(got) == c["len"], c
+            assert hashlib.sha256(got.tobytes()).hexdigest() == c["sha256"], c
+
+
+def run_mjpeg_api(dev, oracle, sizes):
+    """mjpeg_encoder_start_frame / encode_scanline / end_frame, frame after frame
+    on one encoder (IFAST, quality 70, server/mjpeg_encoder.c:33,820)."""
+    enc = B.MJpegEncoder(dev)
+    try:
+        for k, (w, h, fmt) in enumerate(sizes):
+            img = frames.golden_image(w, h, "desktop" if k % 2 else "smooth", k)
+            px = {B.BITMAP_FMT_32BIT: img.reshape(h, -1), B.BITMAP_FMT_RGBA: img.reshape(h, -1),
+                  B.BITMAP_FMT_24BIT: frames.to_bgr24(img), B.BITMAP_FMT_16BIT: frames.to_rgb16(img)}[fmt]
+            got = enc.encode_frame(fmt, w, h, px, px.shape[1])
+            want = oracle.jpeg_encode(px, w, h, px.shape[1], fmt, 70, oracle.DCT_IFAST)
+            assert_same_stream(want, got, "mjpeg frame %d" % k)
+    finally:
+        enc.close()
+
+
+def run_still_api(dev, oracle):
+    """jpeg_encode as red_jpeg_compress_image calls it (server/red_worker.c:6243-6262):
+    quality 85, ISLOW, chunked rows through more_lines, bottom-up bitmaps walked
+    from the last chunk with a negative stride, output through 64 KiB buffers."""
+    enc = B.JpegEncoder(dev)
+    try:
+        for k, (w, h, nch, top_down) in enumerate([(320, 200, 1, True), (333, 77, 3, True),
+                                                   (200, 150, 4, False), (64, 64, 2, False)]):
+            img = frames.golden_image(w, h, "noise" if k == 1 else "desktop", 40 + k)
+            px = img.reshape(h, -1)
+            got = enc.encode(85, B.JPEG_IMAGE_TYPE_BGRX32, w, h, w * 4, split_rows(px, nch),
+                             top_down=top_down)
+            logical = px if top_down else px[::-1]
+            want = oracle.jpeg_encode(np.ascontiguousarray(logical), w, h, w * 4,
+                                      oracle.FMT_32BIT, 85, oracle.DCT_ISLOW)
+            assert_same_stream(want, got, "still %d" % k)
+    finally:
+        enc.close()
+
+
+def run_negative_stride_batch(dev, oracle):
+    w, h = 100, 37
+    px = frames.golden_image(w, h, "smooth", 3).reshape(h, -1)
+    got = batch_encode(dev, [(px, w, h, B.BITMAP_FMT_32BIT, 80, 1, -1)])[0]
+    want = oracle.jpeg_encode(np.ascontiguousarray(px[::-1]), w, h, w * 4, oracle.FMT_32BIT, 80, 1)
+    assert_same_stream(want, got, "bottom-up batch")
+
+
+def run_capacity_error(dev):
+    w, h = 64, 64
+    px = frames.golden_image(w, h, "noise", 1).reshape(h, -1)
+    d_px, d_out = dev.to_device(px), dev.malloc(4096)
+    with pytest.raises(B.SpiceGpuError):
+        B.jpeg_encode_batch(dev, [dict(pixels=d_px, format=8, width=w, height=h, stride=w * 4,
+                                       quality=100, dct=0, out=d_out, out_capacity=700)])
+    dev.free(d_px)
+    dev.free(d_out)
+
+
+# ------------------------------------------------------------------ CPU (sim)
+def test_sim_golden_small(sim, oracle):
+    run_golden(sim, oracle, 64 * 48)
+
+
+def test_sim_mjpeg_api(sim, oracle):
+    run_mjpeg_api(sim, oracle, [(64, 48, 8), (33, 17, 7), (700, 20, 6), (17, 33, 9)])
+
+
+def test_sim_still_api(sim, oracle):
+    run_still_api(sim, oracle)
+
+
+def test_sim_negative_stride_and_capacity(sim, oracle):
+    run_negative_stride_batch(sim, oracle)
+    run_capacity_error(sim)
+
+
+# ------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_gpu_golden_up_to_720p(gpu, oracle):
+    run_golden(gpu, oracle, 1280 * 720)
+
+
+@pytest.mark.gpu
+def test_gpu_golden_4k_and_1080p(gpu, oracle):
+    """BASELINE configs[2]: 3840x2160 frames, IFAST q70 (what the reference's
+    stream encoder emits) and ISLOW q85, against libjpeg's output."""
+    run_golden(gpu, oracle, 3840 * 2160, min_pixels=1280 * 720 + 1, chunk=3)
+
+
+@pytest.mark.gpu
+def test_gpu_mjpeg_api(gpu, oracle):
+    run_mjpeg_api(gpu, oracle, [(640, 480, 8), (333, 177, 7), (1280, 720, 6), (17, 33, 9), (1920, 1080, 8)])
+
+
+@pytest.mark.gpu
+def test_gpu_still_api(gpu, oracle):
+    run_still_api(gpu, oracle)
+
+
+@pytest.mark.gpu
+def test_gpu_negative_stride_and_capacity(gpu, oracle):
+    run_negative_stride_batch(gpu, oracle)
+    run_capacity_error(gpu)
+
+
+@pytest.mark.gpu
+def test_gpu_video_frames_match_oracle(gpu, oracle):
+    seq = frames.VideoSequence(1920, 1080, seed=7)
+    items = []
+    for _ in range(3):
+        f = seq.next().reshape(1080, -1)
+        items.append((f, 1920, 1080, B.BITMAP_FMT_32BIT, 70, 1, 1))
+        items.append((f, 1920, 1080, B.BITMAP_FMT_32BIT, 85, 0, 1))
+    for it, got in zip(items, batch_encode(gpu, items)):
+        want = oracle.jpeg_encode(it[0], it[1], it[2], it[0].shape[1], oracle.FMT_32BIT, it[4], it[5])
+        assert_same_stream(want, got, "video frame")
