@@ -296,6 +296,19 @@ enum { SPICE_GPU_STAT_GLZ = 0, SPICE_GPU_STAT_MJPEG = 1, SPICE_GPU_STAT_JPEG = 2
 void spice_gpu_get_stats(int codec, SpiceGpuCodecStats *out);
 void spice_gpu_reset_stats(void);
 
+/* Kernel timing (no counterpart in the reference): when enabled, every kernel
+ * the library launches is bracketed by HIP events on the library's stream, and
+ * the accumulated device time per kernel name can be read back after the
+ * stream has been synchronised. */
+typedef struct SpiceGpuKernelTime {
+    char name[48];
+    uint64_t launches;
+    double total_ms;
+} SpiceGpuKernelTime;
+void spice_gpu_timing_enable(int on);
+void spice_gpu_timing_reset(void);
+int spice_gpu_timing_read(SpiceGpuKernelTime *out, int max_entries);
+
 #ifdef __cplusplus
 }
 #endif

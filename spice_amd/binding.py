@@ -62,6 +62,10 @@ class SpiceGpuCodecStats(C.Structure):
                 ("total_ns", C.c_uint64), ("min_ns", C.c_uint64), ("max_ns", C.c_uint64)]
 
 
+class SpiceGpuKernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double)]
+
+
 class MJpegEncoderStats(C.Structure):
     _fields_ = [("starting_bit_rate", C.c_uint64), ("cur_bit_rate", C.c_uint64),
                 ("avg_quality", C.c_double)]
@@ -80,6 +84,7 @@ EXPORTS = [
     "spice_gpu_glz_finish", "spice_gpu_jpeg_out_bound", "spice_gpu_jpeg_encode_batch",
     "spice_gpu_jpeg_submit", "spice_gpu_jpeg_finish", "spice_gpu_malloc", "spice_gpu_free",
     "spice_gpu_upload", "spice_gpu_download", "spice_gpu_get_stats", "spice_gpu_reset_stats",
+    "spice_gpu_timing_enable", "spice_gpu_timing_reset", "spice_gpu_timing_read",
 ]
 
 
@@ -143,6 +148,9 @@ class SpiceGpu:
         L.spice_gpu_upload.restype, L.spice_gpu_upload.argtypes = i, [vp, vp, C.c_size_t]
         L.spice_gpu_download.restype, L.spice_gpu_download.argtypes = i, [vp, vp, C.c_size_t]
         L.spice_gpu_get_stats.argtypes = [i, C.POINTER(SpiceGpuCodecStats)]
+        L.spice_gpu_timing_enable.argtypes = [i]
+        L.spice_gpu_timing_read.restype = i
+        L.spice_gpu_timing_read.argtypes = [C.POINTER(SpiceGpuKernelTime), i]
 
     # ---- library state
     def init(self, device=0):
@@ -156,6 +164,12 @@ class SpiceGpu:
         s = SpiceGpuCodecStats()
         self.L.spice_gpu_get_stats(codec, C.byref(s))
         return {k: getattr(s, k) for k, _ in SpiceGpuCodecStats._fields_}
+
+    def kernel_times(self):
+        """{kernel name: (launches, total device ms)} since the last timing reset."""
+        buf = (SpiceGpuKernelTime * 32)()
+        n = self.L.spice_gpu_timing_read(buf, 32)
+        return {buf[k].name.decode(): (buf[k].launches, buf[k].total_ms) for k in range(n)}
 
     # ---- device memory
     def malloc(self, nbytes):

@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include "glz_device.h"
+#include "runtime.h"
 
 #define GLZ_WAVE 64
 
@@ -674,13 +675,17 @@ glz_copy_kernel(const GlzCopyDesc *descs)
 void glz_launch_parse(const GlzDevJob *jobs, int njobs, const uint32_t *u32_pool,
                       const GlzDevSegUpdate *upd_pool, hipStream_t stream)
 {
+    const int t = spicegpu::timing_begin("glz_parse_kernel", stream);
     hipLaunchKernelGGL(glz_parse_kernel, dim3((unsigned)njobs), dim3(GLZ_WAVE), 0, stream, jobs,
                        u32_pool, upd_pool);
+    spicegpu::timing_end(t, stream);
 }
 
 void glz_launch_copy(const GlzCopyDesc *descs, int ndescs, unsigned blocks_per_desc,
                      hipStream_t stream)
 {
+    const int t = spicegpu::timing_begin("glz_copy_kernel", stream);
     hipLaunchKernelGGL(glz_copy_kernel, dim3(blocks_per_desc, (unsigned)ndescs), dim3(256), 0,
                        stream, descs);
+    spicegpu::timing_end(t, stream);
 }

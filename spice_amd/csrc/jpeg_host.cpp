@@ -655,7 +655,6 @@ int spice_gpu_jpeg_finish(SpiceGpuJpegJob *jobs, int njobs)
     bool ok = check(hipStreamSynchronize(stream()), "jpeg batch sync");
     const int32_t *res = (const int32_t *)(f.staging.host + f.results_off);
     int rc = ok ? 0 : -1;
-    uint64_t comp = 0;
     for (int k = 0; k < njobs; k++) {
         jobs[k].out_size = ok ? res[k] : -1;
         if (jobs[k].out_size <= 0) {
@@ -663,8 +662,6 @@ int spice_gpu_jpeg_finish(SpiceGpuJpegJob *jobs, int njobs)
                 set_error("jpeg batch job %d: output does not fit (%d)", k, jobs[k].out_size);
             }
             rc = -1;
-        } else {
-            comp += (uint64_t)jobs[k].out_size;
         }
     }
     if (rc == 0) {

@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include "jpeg_device.h"
+#include "runtime.h"
 
 #define JT JPEG_STRIP_THREADS
 #define JSLOTS (JPEG_STRIP_MCUS + 1)          /* slot 0 is the halo MCU */
@@ -730,13 +731,24 @@ void jpeg_launch(const JpegDevJob *jobs, int njobs, int max_strips, bool any_isl
                  const uint32_t *huff, hipStream_t stream)
 {
     const dim3 grid((unsigned)max_strips, (unsigned)njobs);
+    int t;
     if (any_islow) {
+        t = spicegpu::timing_begin("jpeg_strip_kernel_islow", stream);
         hipLaunchKernelGGL(jpeg_strip_kernel<false>, grid, dim3(JT), 0, stream, jobs, huff);
+        spicegpu::timing_end(t, stream);
     }
     if (any_ifast) {
+        t = spicegpu::timing_begin("jpeg_strip_kernel_ifast", stream);
         hipLaunchKernelGGL(jpeg_strip_kernel<true>, grid, dim3(JT), 0, stream, jobs, huff);
+        spicegpu::timing_end(t, stream);
     }
+    t = spicegpu::timing_begin("jpeg_offsets_kernel", stream);
     hipLaunchKernelGGL(jpeg_offsets_kernel, dim3((unsigned)njobs), dim3(JT), 0, stream, jobs);
+    spicegpu::timing_end(t, stream);
+    t = spicegpu::timing_begin("jpeg_gather_kernel", stream);
     hipLaunchKernelGGL(jpeg_gather_kernel, dim3(64, (unsigned)njobs), dim3(JT), 0, stream, jobs);
+    spicegpu::timing_end(t, stream);
+    t = spicegpu::timing_begin("jpeg_finish_kernel", stream);
     hipLaunchKernelGGL(jpeg_finish_kernel, dim3(64, (unsigned)njobs), dim3(JT), 0, stream, jobs);
+    spicegpu::timing_end(t, stream);
 }

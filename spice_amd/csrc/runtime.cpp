@@ -7,6 +7,9 @@
 #include <string.h>
 #include <time.h>
 
+#include <string>
+#include <vector>
+
 namespace spicegpu {
 
 namespace {
@@ -101,6 +104,83 @@ void stat_add(int codec, uint64_t orig, uint64_t comp, uint64_t ns)
     s.orig_bytes += orig;
     s.comp_bytes += comp;
     s.total_ns += ns;
+}
+
+namespace {
+struct TimedLaunch {
+    int name_id;
+    hipEvent_t a, b;
+};
+std::mutex g_time_mutex;
+bool g_timing = false;
+std::vector<std::string> g_time_names;
+std::vector<SpiceGpuKernelTime> g_time_acc;
+std::vector<TimedLaunch> g_time_pending;
+std::vector<hipEvent_t> g_event_pool;
+
+hipEvent_t take_event()
+{
+    if (!g_event_pool.empty()) {
+        hipEvent_t e = g_event_pool.back();
+        g_event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    hipEventCreate(&e);
+    return e;
+}
+
+/* folds finished launches into the per-name totals; the stream must be idle */
+void timing_collect_locked()
+{
+    for (TimedLaunch &t : g_time_pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
+            g_time_acc[(size_t)t.name_id].launches++;
+            g_time_acc[(size_t)t.name_id].total_ms += (double)ms;
+        }
+        g_event_pool.push_back(t.a);
+        g_event_pool.push_back(t.b);
+    }
+    g_time_pending.clear();
+}
+} // namespace
+
+int timing_begin(const char *kernel_name, hipStream_t s)
+{
+    std::lock_guard<std::mutex> lock(g_time_mutex);
+    if (!g_timing) {
+        return -1;
+    }
+    int id = -1;
+    for (size_t i = 0; i < g_time_names.size(); i++) {
+        if (g_time_names[i] == kernel_name) {
+            id = (int)i;
+        }
+    }
+    if (id < 0) {
+        id = (int)g_time_names.size();
+        g_time_names.push_back(kernel_name);
+        SpiceGpuKernelTime t;
+        memset(&t, 0, sizeof(t));
+        snprintf(t.name, sizeof(t.name), "%s", kernel_name);
+        g_time_acc.push_back(t);
+    }
+    TimedLaunch t{id, take_event(), take_event()};
+    hipEventRecord(t.a, s);
+    g_time_pending.push_back(t);
+    return (int)g_time_pending.size() - 1;
+}
+
+void timing_end(int token, hipStream_t s)
+{
+    if (token < 0) {
+        return;
+    }
+    std::lock_guard<std::mutex> lock(g_time_mutex);
+    if ((size_t)token < g_time_pending.size()) {
+        hipEventRecord(g_time_pending[(size_t)token].b, s);
+    }
 }
 
 bool Staging::reserve(size_t bytes)
@@ -267,6 +347,41 @@ void spice_gpu_reset_stats(void)
 {
     std::lock_guard<std::mutex> lock(g_stat_mutex);
     memset(g_stats, 0, sizeof(g_stats));
+}
+
+void spice_gpu_timing_enable(int on)
+{
+    std::lock_guard<std::mutex> lock(g_time_mutex);
+    g_timing = on != 0;
+}
+
+void spice_gpu_timing_reset(void)
+{
+    std::lock_guard<std::mutex> lock(g_time_mutex);
+    if (g_stream) {
+        hipStreamSynchronize(g_stream);
+    }
+    timing_collect_locked();
+    for (SpiceGpuKernelTime &t : g_time_acc) {
+        t.launches = 0;
+        t.total_ms = 0.0;
+    }
+}
+
+int spice_gpu_timing_read(SpiceGpuKernelTime *out, int max_entries)
+{
+    std::lock_guard<std::mutex> lock(g_time_mutex);
+    if (g_stream) {
+        hipStreamSynchronize(g_stream);
+    }
+    timing_collect_locked();
+    int n = 0;
+    for (const SpiceGpuKernelTime &t : g_time_acc) {
+        if (n < max_entries) {
+            out[n++] = t;
+        }
+    }
+    return n;
 }
 
 } // extern "C"

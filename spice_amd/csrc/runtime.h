@@ -27,6 +27,10 @@ bool check(hipError_t e, const char *what);
 std::mutex &device_mutex();
 
 void stat_add(int codec, uint64_t orig, uint64_t comp, uint64_t ns);
+
+/* Brackets one kernel launch with events when timing is enabled (no-ops otherwise). */
+int timing_begin(const char *kernel_name, hipStream_t s);
+void timing_end(int token, hipStream_t s);
 uint64_t now_ns();
 
 /* Host-pinned buffer with a device mirror, grown geometrically. */
