@@ -24,7 +24,7 @@
 
 using namespace spicegpu;
 
-void glz_launch_parse(const GlzDevJob *jobs, int njobs, const uint32_t *u32_pool,
+void glz_launch_parse(const GlzDevJob *jobs, int njobs, unsigned type_mask, const uint32_t *u32_pool,
                       const GlzDevSegUpdate *upd_pool, hipStream_t stream);
 void glz_launch_copy(const GlzCopyDesc *descs, int ndescs, unsigned blocks_per_desc,
                      hipStream_t stream);
@@ -616,7 +616,11 @@ bool launch(std::vector<Prepared> &jobs, Staging &st, size_t *results_off, bool 
         blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
         glz_launch_copy((const GlzCopyDesc *)(st.dev + off_copy), (int)n_copy, blocks, s);
     }
-    glz_launch_parse((const GlzDevJob *)(st.dev + off_jobs), (int)n,
+    unsigned type_mask = 0;
+    for (Prepared &p : jobs) {
+        type_mask |= 1u << p.dev.type;
+    }
+    glz_launch_parse((const GlzDevJob *)(st.dev + off_jobs), (int)n, type_mask,
                      (const uint32_t *)(st.dev + off_u32),
                      (const GlzDevSegUpdate *)(st.dev + off_upd), s);
     if (!check(hipGetLastError(), "glz launch")) {

@@ -1,21 +1,25 @@
 /*
- * GLZ parse for gfx950: one wavefront per image, one image per dictionary.
+ * GLZ parse for gfx950: one 256-lane workgroup per image, one image per
+ * dictionary.
  *
  * The reference parser (server/glz_encode_tmpl.c:268-491) is a strictly serial
  * walk: at every "stop" it probes a single-slot hash table whose contents
  * depend on all earlier stops.  This kernel keeps that order -- the output is
- * byte-identical -- but evaluates 64 consecutive positions per step:
+ * byte-identical -- but evaluates GLZ_WIN consecutive positions per step:
  *
- *   1. every lane takes one position of the window [ip, ip+64): run test,
- *      3-pixel hash, hash-table probe, reference validation
- *      (REF_SEG_IS_VALID, glz_encoder_dictionary_protected.h:176-184) and the
- *      first pixel compares of do_match (glz_encode_tmpl.c:147-229), all as
- *      parallel gathers;
- *   2. a wave-uniform resolver then visits the real stops in order.  A probe
- *      answered in step 1 is still the truth unless a stop *inside the
- *      window* stored the same hash since; one ballot finds that case;
- *   3. match extension, run extension and the literal/match byte emission are
- *      cooperative (64 pixels compared or written per instruction).
+ *   1. gather (all four wavefronts): every lane takes one position of the
+ *      window [ip, ip+256): run test, 3-pixel hash, hash-table probe, reference
+ *      validation (REF_SEG_IS_VALID, glz_encoder_dictionary_protected.h:176-184),
+ *      do_match's distance rules (glz_encode_tmpl.c:147-229) and the first
+ *      GLZ_K pixels of the match extension, all as parallel gathers from HBM;
+ *      the window's own pixels are staged in LDS;
+ *   2. resolve (wavefront 0): visits the real stops in order out of LDS.  A
+ *      probe answered in step 1 is still the truth unless a stop *inside the
+ *      window* stored the same hash since; ballots over the window's hashes
+ *      find that case, and the compare then runs on the LDS tile;
+ *   3. matches that outgrow step 1 (the few long ones that cover most pixels)
+ *      are extended 512 pixels per iteration; literal and match bytes are
+ *      written cooperatively.
  *
  * Hash-table stores are issued by lane 0 only, in stop order, so that memory
  * sees them in the order the reference performs them.
@@ -26,6 +30,27 @@
 #include "runtime.h"
 
 #define GLZ_WAVE 64
+#define GLZ_THREADS 256
+#define GLZ_WIN 256                       /* window positions per step */
+#define GLZ_K 8                           /* pixels every lane pre-compares against its candidate */
+#define GLZ_TILE (GLZ_WIN + GLZ_K + 4)    /* LDS pixels: positions ip-1 .. ip+WIN+K+2 */
+#define GLZ_SEG_CACHE 64                  /* segment slots mirrored in LDS */
+#define GLZ_UNROLL 8                      /* 64-pixel rows per iteration of the long compares */
+
+#define GLZ_F_ACT 1u
+#define GLZ_F_RLE 2u
+#define GLZ_F_GOK 4u
+#define GLZ_F_MAXED 8u
+
+/* what step 1 leaves in LDS for each window position */
+struct GlzPosInfo {
+    uint32_t h;
+    uint32_t flags;    /* GLZ_F_* | pre-compared length << 8 */
+    uint32_t g_ref;
+    uint32_t g_seg;
+    uint32_t g_image_dist;
+    uint32_t g_pix_dist;
+};
 
 enum { GLZ_MODE_RGB32 = 0, GLZ_MODE_RGB24 = 1, GLZ_MODE_RGB16 = 2, GLZ_MODE_ALPHA = 3 };
 
@@ -220,49 +245,116 @@ __device__ void glz_put_match(GlzOut &o, uint32_t image_dist, uint32_t pix_dist,
     glz_advance(o, n);
 }
 
-/* Writes the literal pixels of the lanes in `mask` (window order) and the
- * copy-count bytes that fall between them, glz_encode_tmpl.c:449-462. */
+/* 256-bit window masks as four words, touched only through compile-time
+ * indices so that they stay in registers */
+struct GlzMask {
+    uint64_t w0, w1, w2, w3;
+};
+__device__ __forceinline__ bool glz_mask_test(const GlzMask &m, int i)
+{
+    const int w = i >> 6;
+    const uint64_t v = w == 0 ? m.w0 : (w == 1 ? m.w1 : (w == 2 ? m.w2 : m.w3));
+    return (v >> (i & 63)) & 1;
+}
+__device__ __forceinline__ void glz_mask_set(GlzMask &m, int i)
+{
+    const int w = i >> 6;
+    const uint64_t b = 1ull << (i & 63);
+    m.w0 |= w == 0 ? b : 0;
+    m.w1 |= w == 1 ? b : 0;
+    m.w2 |= w == 2 ? b : 0;
+    m.w3 |= w == 3 ? b : 0;
+}
+__device__ __forceinline__ void glz_mask_clear(GlzMask &m)
+{
+    m.w0 = m.w1 = m.w2 = m.w3 = 0;
+}
+/* bits of m strictly below position i */
+__device__ __forceinline__ GlzMask glz_mask_below(const GlzMask &m, int i)
+{
+    const int w = i >> 6;
+    const uint64_t part = (1ull << (i & 63)) - 1;
+    GlzMask r;
+    r.w0 = w > 0 ? m.w0 : (m.w0 & part);
+    r.w1 = w > 1 ? m.w1 : (w == 1 ? (m.w1 & part) : 0);
+    r.w2 = w > 2 ? m.w2 : (w == 2 ? (m.w2 & part) : 0);
+    r.w3 = w == 3 ? (m.w3 & part) : 0;
+    return r;
+}
+
+/* Literal pixels of the window positions in mask[] (bit p of word p/64), in
+ * order, with the copy-count bytes that fall between them
+ * (glz_encode_tmpl.c:449-462).  Wavefront 0 only; pixels come from the LDS tile. */
 template <int MODE>
-__device__ __forceinline__ void glz_flush_literals(GlzOut &o, int &copy, uint64_t mask,
-                                                   uint32_t raw, int lane)
+__device__ __forceinline__ void glz_flush_literals(GlzOut &o, int &copy, const GlzMask &lit,
+                                                   const uint32_t *tile, int lane)
 {
     typedef GlzTraits<MODE> T;
-    const int n = __popcll(mask);
+    const uint64_t mask[4] = {lit.w0, lit.w1, lit.w2, lit.w3};
+    const int n0 = __popcll(mask[0]), n1 = __popcll(mask[1]), n2 = __popcll(mask[2]);
+    const int n = n0 + n1 + n2 + __popcll(mask[3]);
     if (n == 0) {
         return;
     }
-    if ((mask >> lane) & 1) {
-        const int k = __popcll(mask & ((1ull << lane) - 1));
-        uint32_t pos = o.op + (uint32_t)k * T::LITB + (uint32_t)((copy + k) >> 5);
-        if (MODE == GLZ_MODE_RGB32 || MODE == GLZ_MODE_RGB24) {
-            glz_put(o, pos, raw & 0xff);
-            glz_put(o, pos + 1, (raw >> 8) & 0xff);
-            glz_put(o, pos + 2, (raw >> 16) & 0xff);
-        } else if (MODE == GLZ_MODE_RGB16) {
-            glz_put(o, pos, (raw >> 8) & 0xff);
-            glz_put(o, pos + 1, raw & 0xff);
-        } else {
-            glz_put(o, pos, raw & 0xff);
+    const int total_ctrl = (copy + n) >> 5;
+    int before = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        if ((mask[w] >> lane) & 1) {
+            const int k = before + __popcll(mask[w] & ((1ull << lane) - 1));
+            const uint32_t raw = tile[w * 64 + lane + 1];
+            const uint32_t pos = o.op + (uint32_t)k * T::LITB + (uint32_t)((copy + k) >> 5);
+            if (MODE == GLZ_MODE_RGB32 || MODE == GLZ_MODE_RGB24) {
+                glz_put(o, pos, raw & 0xff);
+                glz_put(o, pos + 1, (raw >> 8) & 0xff);
+                glz_put(o, pos + 2, (raw >> 16) & 0xff);
+            } else if (MODE == GLZ_MODE_RGB16) {
+                glz_put(o, pos, (raw >> 8) & 0xff);
+                glz_put(o, pos + 1, raw & 0xff);
+            } else {
+                glz_put(o, pos, raw & 0xff);
+            }
+            /* a full run of 32 is followed by the next run's count byte; the last
+             * one of this flush may still be patched, so lane 0 owns it (below) */
+            if (((copy + k + 1) & 31) == 0 && ((copy + k + 1) >> 5) < total_ctrl) {
+                glz_put(o, pos + T::LITB, GLZ_MAX_COPY - 1);
+            }
         }
-        /* a full run of 32 is followed by the next run's count byte; the last
-         * one of this flush may still be patched, so lane 0 owns it (below) */
-        if (((copy + k + 1) & 31) == 0 && ((copy + k + 1) >> 5) < ((copy + n) >> 5)) {
-            glz_put(o, pos + T::LITB, GLZ_MAX_COPY - 1);
-        }
+        before += w == 0 ? n0 : (w == 1 ? n1 : n2);
     }
-    const int nctrl = (copy + n) >> 5;
-    if (nctrl) {
-        const int kk = 32 * nctrl - copy - 1; /* literal after which the last count byte sits */
+    if (total_ctrl) {
+        const int kk = 32 * total_ctrl - copy - 1; /* literal after which the last count byte sits */
         o.last_copy = o.op + (uint32_t)kk * T::LITB + (uint32_t)((copy + kk) >> 5) + T::LITB;
         if (lane == 0) {
             glz_put(o, o.last_copy, GLZ_MAX_COPY - 1);
         }
     }
-    glz_advance(o, (uint32_t)n * T::LITB + (uint32_t)nctrl);
+    glz_advance(o, (uint32_t)n * T::LITB + (uint32_t)total_ctrl);
     copy = (copy + n) & 31;
 }
 
-/* Number of leading positions k < maxn with src[sidx+k] == ref[ridx+k]. */
+/* Up to 64 literal pixels straight from the window arena (segment heads and
+ * tails), glz_encode_tmpl.c:466-487,511-541.  Wavefront 0 only. */
+template <int MODE>
+__device__ __forceinline__ void glz_literals_from_arena(GlzOut &o, int &copy, const uint8_t *base,
+                                                        int first, int count, uint32_t *scratch,
+                                                        int lane)
+{
+    if (count <= 0) {
+        return;
+    }
+    /* reuse the tile layout expected by glz_flush_literals: pixel p at scratch[p + 1] */
+    if (lane < count) {
+        scratch[lane + 1] = glz_load_px<MODE>(base, first + lane);
+    }
+    GlzMask mask;
+    glz_mask_clear(mask);
+    mask.w0 = count >= 64 ? ~0ull : ((1ull << count) - 1);
+    glz_flush_literals<MODE>(o, copy, mask, scratch, lane);
+}
+
+/* Number of leading positions k in [start, maxn) with src[sidx+k] == ref[ridx+k],
+ * plus start; 512 pixels per iteration.  Wavefront 0 only. */
 template <int MODE>
 __device__ int glz_match_len(const uint8_t *sbase, int sidx, const uint8_t *rbase, int ridx,
                              int start, int maxn, int lane)
@@ -270,40 +362,68 @@ __device__ int glz_match_len(const uint8_t *sbase, int sidx, const uint8_t *rbas
     typedef GlzTraits<MODE> T;
     int n = start;
     while (n < maxn) {
-        const int k = n + lane;
-        bool eq = false;
-        if (k < maxn) {
-            eq = ((glz_load_px<MODE>(sbase, sidx + k) ^ glz_load_px<MODE>(rbase, ridx + k)) &
-                  T::MASK) == 0;
+        uint64_t miss[GLZ_UNROLL];
+#pragma unroll
+        for (int u = 0; u < GLZ_UNROLL; u++) {
+            const int k = n + u * 64 + lane;
+            bool eq = false;
+            if (k < maxn) {
+                eq = ((glz_load_px<MODE>(sbase, sidx + k) ^ glz_load_px<MODE>(rbase, ridx + k)) &
+                      T::MASK) == 0;
+            }
+            miss[u] = __ballot(!eq);
         }
-        const uint64_t miss = __ballot(!eq);
-        if (miss) {
-            n += __ffsll((unsigned long long)miss) - 1;
+        bool stop = false;
+#pragma unroll
+        for (int u = 0; u < GLZ_UNROLL; u++) {
+            if (!stop) {
+                if (miss[u]) {
+                    n += __ffsll((unsigned long long)miss[u]) - 1;
+                    stop = true;
+                } else {
+                    n += 64;
+                }
+            }
+        }
+        if (stop) {
             break;
         }
-        n += GLZ_WAVE;
     }
     return n < maxn ? n : maxn;
 }
 
-/* Number of leading positions k < maxn with src[sidx+k] == x. */
+/* Number of leading positions k < maxn with src[sidx+k] == x.  Wavefront 0 only. */
 template <int MODE>
 __device__ int glz_run_len(const uint8_t *sbase, int sidx, uint32_t x, int maxn, int lane)
 {
     typedef GlzTraits<MODE> T;
     int n = 0;
     while (n < maxn) {
-        const int k = n + lane;
-        bool eq = false;
-        if (k < maxn) {
-            eq = ((glz_load_px<MODE>(sbase, sidx + k) ^ x) & T::MASK) == 0;
+        uint64_t miss[GLZ_UNROLL];
+#pragma unroll
+        for (int u = 0; u < GLZ_UNROLL; u++) {
+            const int k = n + u * 64 + lane;
+            bool eq = false;
+            if (k < maxn) {
+                eq = ((glz_load_px<MODE>(sbase, sidx + k) ^ x) & T::MASK) == 0;
+            }
+            miss[u] = __ballot(!eq);
         }
-        const uint64_t miss = __ballot(!eq);
-        if (miss) {
-            n += __ffsll((unsigned long long)miss) - 1;
+        bool stop = false;
+#pragma unroll
+        for (int u = 0; u < GLZ_UNROLL; u++) {
+            if (!stop) {
+                if (miss[u]) {
+                    n += __ffsll((unsigned long long)miss[u]) - 1;
+                    stop = true;
+                } else {
+                    n += 64;
+                }
+            }
+        }
+        if (stop) {
             break;
         }
-        n += GLZ_WAVE;
     }
     return n < maxn ? n : maxn;
 }
@@ -318,71 +438,92 @@ __device__ __forceinline__ uint32_t glz_hash_at(const uint8_t *base, int idx)
                            glz_load_px<MODE>(base, idx + 2) & T::MASK);
 }
 
-/* One segment, glz_encode_tmpl.c:268-491. */
+/* LDS shared by the workgroup */
+struct GlzShared {
+    uint32_t tile[GLZ_TILE];
+    GlzPosInfo info[GLZ_WIN];
+    GlzDevSeg seg_cache[GLZ_SEG_CACHE];
+    int next_ip;
+};
+
+__shared__ GlzShared glz_sh;
+
+__device__ __forceinline__ GlzDevSeg glz_seg(const GlzDevJob &job, const GlzShared &sh, uint32_t idx)
+{
+    if (idx < GLZ_SEG_CACHE) {
+        return sh.seg_cache[idx];
+    }
+    return job.segs[idx];
+}
+
+/* Matching pixels between window positions i and j < i, read from the LDS tile
+ * as far as it reaches; *checked = how many positions the tile could vouch for. */
 template <int MODE>
-__device__ void glz_parse_seg(const GlzDevJob &job, uint32_t seg_idx, int from, int copied,
-                              GlzOut &o, int lane)
+__device__ __forceinline__ int glz_tile_match_len(const uint32_t *tile, int i, int j, int maxn,
+                                                  int lane, int *checked)
 {
     typedef GlzTraits<MODE> T;
-    const GlzDevSeg cs = job.segs[seg_idx];
+    int lim = GLZ_TILE - (i + 1);
+    lim = lim < maxn ? lim : maxn;
+    lim = lim < 64 ? lim : 64;
+    bool eq = false;
+    if (lane < lim) {
+        eq = ((tile[i + 1 + lane] ^ tile[j + 1 + lane]) & T::MASK) == 0;
+    }
+    const uint64_t miss = __ballot(!eq);
+    const int n = miss ? __ffsll((unsigned long long)miss) - 1 : 64;
+    *checked = lim;
+    return n < lim ? n : lim;
+}
+
+/* One segment, glz_encode_tmpl.c:268-491.  All 256 lanes call this; GlzOut and
+ * copy live in wavefront 0. */
+template <int MODE>
+__device__ __forceinline__ void glz_parse_seg(const GlzDevJob &job, uint32_t seg_idx, int from,
+                                              int copied, GlzOut &o, int tid)
+{
+    GlzShared &sh = glz_sh;
+    typedef GlzTraits<MODE> T;
+    const int lane = tid & 63;
+    const bool w0 = tid < GLZ_WAVE;
+    const GlzDevSeg cs = glz_seg(job, sh, seg_idx);
     const uint8_t *base = job.arena + (size_t)cs.arena_off16 * 16;
     const int npix = (int)cs.nunits;
     const int ip_bound = npix - 2, ip_limit = npix - 6;
     int ip = from;
     int copy = copied;
 
-    if (copy == 0) {
+    if (w0 && copy == 0) {
         glz_put_copy_count(o, GLZ_MAX_COPY - 1, lane);
     }
 
     while (ip < ip_limit) {
-        /* ---------------- step 1: the window, one position per lane */
-        const int q = ip + lane;
-        const bool act = q < ip_limit;
-        uint32_t raw0 = 0, ext = 0;
-        if (q < npix) {
-            raw0 = glz_load_px<MODE>(base, q);
+        /* ---------------- step 1: stage the window's pixels, one position per lane */
+        for (int t = tid; t < GLZ_TILE; t += GLZ_THREADS) {
+            const int pos = ip - 1 + t;
+            sh.tile[t] = (pos >= 0 && pos < npix) ? glz_load_px<MODE>(base, pos) : 0u;
         }
+        __syncthreads();
         {
-            /* pixels just outside the window that its edge lanes need */
-            int e = lane == 0 ? ip + 64 : lane == 1 ? ip + 65 : lane == 2 ? ip - 1 : -1;
-            if (lane < 3 && e >= 0 && e < npix) {
-                ext = glz_load_px<MODE>(base, e);
-            }
-        }
-        const uint32_t c0 = raw0 & T::MASK;
-        const uint32_t d1 = __shfl_down(c0, 1), d2 = __shfl_down(c0, 2), u1 = __shfl_up(c0, 1);
-        const uint32_t e0 = __shfl(ext, 0) & T::MASK, e1 = __shfl(ext, 1) & T::MASK;
-        const uint32_t e2 = __shfl(ext, 2) & T::MASK;
-        const uint32_t c1 = lane < 63 ? d1 : e0;
-        const uint32_t c2 = lane < 62 ? d2 : (lane == 62 ? e0 : e1);
-        const uint32_t cm1 = lane > 0 ? u1 : e2;
-
-        const bool rle = act && q > 0 && cm1 == c0 && c0 == c1 && c1 == c2;
-        const uint32_t h = glz_hash3<MODE>(c0, c1, c2);
-
-        /* hash probe + do_match up to (not including) the extension loop */
-        bool gok = false;
-        uint32_t g_image_dist = 0, g_pix_dist = 0, g_ref = 0, g_seg = 0;
-        if (act && !rle) {
-            const uint2 he = job.htab[h];
-            const GlzDevSeg rs = job.segs[he.x];
-            const bool valid =
-                he.x == seg_idx ||
-                ((rs.flags & GLZ_SEG_USED) && (rs.flags & GLZ_SEG_ALIVE) &&
-                 (rs.flags & GLZ_SEG_TYPE_MASK) == (cs.flags & GLZ_SEG_TYPE_MASK) &&
-                 rs.pixels_so_far <= cs.pixels_so_far && job.head_psf <= rs.pixels_so_far);
-            const int ref = (int)he.y;
-            if (valid && (int64_t)he.y <= (int64_t)rs.nunits - T::MIN_REF) {
-                const uint8_t *rbase = job.arena + (size_t)rs.arena_off16 * 16;
-                bool same = ((glz_load_px<MODE>(rbase, ref) & T::MASK) == c0) &&
-                            ((glz_load_px<MODE>(rbase, ref + 1) & T::MASK) == c1);
-                if (T::MIN_REF == 4) {
-                    same = same && ((glz_load_px<MODE>(rbase, ref + 2) & T::MASK) == c2) &&
-                           (((glz_load_px<MODE>(rbase, ref + 3) ^
-                              glz_load_px<MODE>(base, q + 3)) & T::MASK) == 0);
-                }
-                if (same) {
+            const int p = tid, q = ip + p;
+            const bool act = q < ip_limit;
+            const uint32_t cm1 = sh.tile[p] & T::MASK, c0 = sh.tile[p + 1] & T::MASK;
+            const uint32_t c1 = sh.tile[p + 2] & T::MASK, c2 = sh.tile[p + 3] & T::MASK;
+            const bool rle = act && q > 0 && cm1 == c0 && c0 == c1 && c1 == c2;
+            GlzPosInfo pi;
+            pi.h = glz_hash3<MODE>(c0, c1, c2);
+            pi.flags = (act ? GLZ_F_ACT : 0u) | (rle ? GLZ_F_RLE : 0u);
+            pi.g_ref = pi.g_seg = pi.g_image_dist = pi.g_pix_dist = 0;
+            if (act && !rle) {
+                /* hash probe + do_match (glz_encode_tmpl.c:147-241) against the slot's content */
+                const uint2 he = job.htab[pi.h];
+                const GlzDevSeg rs = glz_seg(job, sh, he.x);
+                const bool valid =
+                    he.x == seg_idx ||
+                    ((rs.flags & GLZ_SEG_USED) && (rs.flags & GLZ_SEG_ALIVE) &&
+                     (rs.flags & GLZ_SEG_TYPE_MASK) == (cs.flags & GLZ_SEG_TYPE_MASK) &&
+                     rs.pixels_so_far <= cs.pixels_so_far && job.head_psf <= rs.pixels_so_far);
+                if (valid && (int64_t)he.y <= (int64_t)rs.nunits - T::MIN_REF) {
                     const uint64_t idist = cs.image_id - rs.image_id;
                     uint64_t pdist;
                     if (idist == 0) {
@@ -391,201 +532,276 @@ __device__ void glz_parse_seg(const GlzDevJob &job, uint32_t seg_idx, int from, 
                         pdist = (uint64_t)he.y + rs.img_first_delta;
                     }
                     if (pdist != 0 && pdist < 33554432ull && idist <= 16777215ull) {
-                        gok = true;
-                        g_image_dist = (uint32_t)idist;
-                        g_pix_dist = (uint32_t)pdist;
-                        g_ref = he.y;
-                        g_seg = he.x;
+                        const uint8_t *rbase = job.arena + (size_t)rs.arena_off16 * 16;
+                        const int ref = (int)he.y;
+                        int maxk = ip_bound - q;
+                        const int rmax = (int)rs.nunits - ref;
+                        maxk = rmax < maxk ? rmax : maxk;
+                        const bool capped = maxk > GLZ_K;
+                        maxk = capped ? GLZ_K : maxk;
+                        uint32_t r[GLZ_K];
+#pragma unroll
+                        for (int k = 0; k < GLZ_K; k++) {
+                            r[k] = glz_load_px<MODE>(rbase, ref + (k < maxk ? k : 0));
+                        }
+                        int glen = 0;
+                        bool run = true;
+#pragma unroll
+                        for (int k = 0; k < GLZ_K; k++) {
+                            run = run && k < maxk && ((r[k] ^ sh.tile[p + 1 + k]) & T::MASK) == 0;
+                            glen += run ? 1 : 0;
+                        }
+                        if (glen >= T::MIN_REF) {
+                            pi.flags |= GLZ_F_GOK | ((uint32_t)glen << 8);
+                            if (capped && glen == GLZ_K) {
+                                pi.flags |= GLZ_F_MAXED;
+                            }
+                            pi.g_ref = he.y;
+                            pi.g_seg = he.x;
+                            pi.g_image_dist = (uint32_t)idist;
+                            pi.g_pix_dist = (uint32_t)pdist;
+                        }
                     }
                 }
             }
+            sh.info[p] = pi;
         }
-        const uint64_t act_mask = __ballot(act);
-        const uint64_t rle_mask = __ballot(rle);
-        const uint64_t gok_mask = __ballot(gok);
+        __syncthreads();
 
-        /* ---------------- step 2: visit the stops in order */
-        uint64_t inserted = 0; /* window lanes whose hash slot was stored in this step */
-        uint64_t lit_mask = 0; /* window lanes pending emission as literals */
-        int i = 0;
-        while (i < 64 && ((act_mask >> i) & 1)) {
-            const int anchor = ip + i;
-            int len = 0;
-            uint32_t image_dist = 0, pix_dist = 0;
+        /* ---------------- step 2: wavefront 0 visits the stops in order */
+        if (w0) {
+            const uint32_t h0r = sh.info[lane].h, h1r = sh.info[64 + lane].h;
+            const uint32_t h2r = sh.info[128 + lane].h, h3r = sh.info[192 + lane].h;
+            const uint32_t f0 = sh.info[lane].flags, f1 = sh.info[64 + lane].flags;
+            const uint32_t f2 = sh.info[128 + lane].flags, f3 = sh.info[192 + lane].flags;
+            GlzMask act_m, rle_m, gok_m;
+            act_m.w0 = __ballot(f0 & GLZ_F_ACT); act_m.w1 = __ballot(f1 & GLZ_F_ACT);
+            act_m.w2 = __ballot(f2 & GLZ_F_ACT); act_m.w3 = __ballot(f3 & GLZ_F_ACT);
+            rle_m.w0 = __ballot(f0 & GLZ_F_RLE); rle_m.w1 = __ballot(f1 & GLZ_F_RLE);
+            rle_m.w2 = __ballot(f2 & GLZ_F_RLE); rle_m.w3 = __ballot(f3 & GLZ_F_RLE);
+            gok_m.w0 = __ballot(f0 & GLZ_F_GOK); gok_m.w1 = __ballot(f1 & GLZ_F_GOK);
+            gok_m.w2 = __ballot(f2 & GLZ_F_GOK); gok_m.w3 = __ballot(f3 & GLZ_F_GOK);
+            GlzMask inserted, lit; /* slots stored in this step; positions pending as literals */
+            glz_mask_clear(inserted);
+            glz_mask_clear(lit);
+            int i = 0;
+            while (i < GLZ_WIN && glz_mask_test(act_m, i)) {
+                const int anchor = ip + i;
+                int len = 0;
+                uint32_t image_dist = 0, pix_dist = 0;
 
-            if ((rle_mask >> i) & 1) {
-                /* glz_encode_tmpl.c:310-335 */
-                const uint32_t x = __shfl(c2, i);
-                len = 3 + glz_run_len<MODE>(base, anchor + 3, x, ip_bound - (anchor + 3), lane);
-                pix_dist = 1;
-                image_dist = 0;
-            } else {
-                const uint32_t hi = __shfl(h, i);
-                const uint64_t same_h =
-                    __ballot(h == hi) & inserted & ((1ull << i) - 1);
-                if (same_h) {
-                    /* the slot was overwritten by a stop inside this window */
-                    const int j = 63 - __clzll((long long)same_h);
-                    const int ref = ip + j;
-                    const int maxn = ip_bound - anchor; /* ref < anchor, so its limit is laxer */
-                    len = glz_match_len<MODE>(base, anchor, base, ref, 0, maxn, lane);
-                    if (len < T::MIN_REF) {
-                        len = 0;
+                if (glz_mask_test(rle_m, i)) {
+                    /* glz_encode_tmpl.c:310-335 */
+                    const uint32_t x = sh.tile[i + 3];
+                    const int maxn = ip_bound - (anchor + 3);
+                    int lim = GLZ_TILE - (i + 4);
+                    lim = lim < maxn ? lim : maxn;
+                    lim = lim < 64 ? lim : 64;
+                    bool eq = false;
+                    if (lane < lim) {
+                        eq = ((sh.tile[i + 4 + lane] ^ x) & T::MASK) == 0;
                     }
+                    const uint64_t miss = __ballot(!eq);
+                    int n = miss ? __ffsll((unsigned long long)miss) - 1 : 64;
+                    n = n < lim ? n : lim;
+                    if (n == lim && lim < maxn) {
+                        n += glz_run_len<MODE>(base, anchor + 3 + n, x, maxn - n, lane);
+                    }
+                    len = 3 + n;
+                    pix_dist = 1;
                     image_dist = 0;
-                    pix_dist = (uint32_t)(i - j);
-                } else if ((gok_mask >> i) & 1) {
-                    const uint32_t rseg = __shfl(g_seg, i);
-                    const int ref = (int)__shfl(g_ref, i);
-                    const GlzDevSeg rs = job.segs[rseg];
-                    const uint8_t *rbase = job.arena + (size_t)rs.arena_off16 * 16;
-                    int maxn = ip_bound - anchor;
-                    const int rmax = (int)rs.nunits - ref;
-                    maxn = rmax < maxn ? rmax : maxn;
-                    len = glz_match_len<MODE>(base, anchor, rbase, ref, T::MIN_REF, maxn, lane);
-                    image_dist = __shfl(g_image_dist, i);
-                    pix_dist = __shfl(g_pix_dist, i);
-                }
-                if (len > 0 && len <= T::MAX_REF) {
-                    /* glz_encode_tmpl.c:243-261 */
-                    const int need = glz_ref_bytes(image_dist, pix_dist) / T::ENC_DIV + 1;
-                    if (len < need) {
-                        len = 0;
-                    }
-                }
-                /* glz_encode_tmpl.c:381 */
-                if (lane == 0) {
-                    job.htab[hi] = make_uint2(seg_idx, (uint32_t)anchor);
-                }
-                inserted |= 1ull << i;
-            }
-
-            if (len == 0) {
-                lit_mask |= 1ull << i;
-                i++;
-                continue;
-            }
-
-            /* ---- match, glz_encode_tmpl.c:387-447 */
-            glz_flush_literals<MODE>(o, copy, lit_mask, raw0, lane);
-            lit_mask = 0;
-            if (image_dist == 0) {
-                pix_dist--;
-            }
-            glz_close_copy(o, copy, lane);
-            copy = 0;
-            glz_put_match(o, image_dist, pix_dist, (uint32_t)(len - T::LEN_BIAS), lane);
-
-            {
-                const int p0 = anchor + len - 2, p1 = p0 + 1;
-                const bool ins0 = !T::GUARD_A || p0 > anchor;
-                const bool ins1 = !T::GUARD_B || p1 > anchor;
-                uint32_t h0, h1;
-                if (p1 - ip < 64 && ((act_mask >> (p1 - ip)) & 1)) {
-                    h0 = __shfl(h, p0 - ip);
-                    h1 = __shfl(h, p1 - ip);
                 } else {
-                    h0 = glz_hash_at<MODE>(base, p0);
-                    h1 = glz_hash_at<MODE>(base, p1);
-                }
-                if (lane == 0) {
-                    if (ins0) {
-                        job.htab[h0] = make_uint2(seg_idx, (uint32_t)p0);
+                    const uint32_t hi = sh.info[i].h;
+                    /* most recent store to this slot made inside the window, if any */
+                    int j = -1;
+                    {
+                        const GlzMask below = glz_mask_below(inserted, i);
+                        const uint64_t m0 = __ballot(h0r == hi) & below.w0;
+                        const uint64_t m1 = __ballot(h1r == hi) & below.w1;
+                        const uint64_t m2 = __ballot(h2r == hi) & below.w2;
+                        const uint64_t m3 = __ballot(h3r == hi) & below.w3;
+                        if (m3) {
+                            j = 192 + 63 - __clzll((long long)m3);
+                        } else if (m2) {
+                            j = 128 + 63 - __clzll((long long)m2);
+                        } else if (m1) {
+                            j = 64 + 63 - __clzll((long long)m1);
+                        } else if (m0) {
+                            j = 63 - __clzll((long long)m0);
+                        }
                     }
-                    if (ins1) {
-                        job.htab[h1] = make_uint2(seg_idx, (uint32_t)p1);
+                    if (j >= 0) {
+                        const int maxn = ip_bound - anchor; /* ref < anchor: its own limit is laxer */
+                        int checked = 0;
+                        len = glz_tile_match_len<MODE>(sh.tile, i, j, maxn, lane, &checked);
+                        if (len == checked && checked < maxn) {
+                            len = glz_match_len<MODE>(base, anchor, base, ip + j, len, maxn, lane);
+                        }
+                        if (len < T::MIN_REF) {
+                            len = 0;
+                        }
+                        image_dist = 0;
+                        pix_dist = (uint32_t)(i - j);
+                    } else if (glz_mask_test(gok_m, i)) {
+                        const GlzPosInfo pi = sh.info[i];
+                        len = (int)(pi.flags >> 8);
+                        image_dist = pi.g_image_dist;
+                        pix_dist = pi.g_pix_dist;
+                        if (pi.flags & GLZ_F_MAXED) {
+                            const GlzDevSeg rs = glz_seg(job, sh, pi.g_seg);
+                            const uint8_t *rbase = job.arena + (size_t)rs.arena_off16 * 16;
+                            int maxn = ip_bound - anchor;
+                            const int rmax = (int)rs.nunits - (int)pi.g_ref;
+                            maxn = rmax < maxn ? rmax : maxn;
+                            len = glz_match_len<MODE>(base, anchor, rbase, (int)pi.g_ref, len, maxn, lane);
+                        }
+                    }
+                    if (len > 0 && len <= T::MAX_REF) {
+                        /* glz_encode_tmpl.c:243-261 */
+                        const int need = glz_ref_bytes(image_dist, pix_dist) / T::ENC_DIV + 1;
+                        if (len < need) {
+                            len = 0;
+                        }
+                    }
+                    /* glz_encode_tmpl.c:381 */
+                    if (lane == 0) {
+                        job.htab[hi] = make_uint2(seg_idx, (uint32_t)anchor);
+                    }
+                    glz_mask_set(inserted, i);
+                }
+
+                if (len == 0) {
+                    glz_mask_set(lit, i);
+                    i++;
+                    continue;
+                }
+
+                /* ---- match, glz_encode_tmpl.c:387-447 */
+                glz_flush_literals<MODE>(o, copy, lit, sh.tile, lane);
+                glz_mask_clear(lit);
+                if (image_dist == 0) {
+                    pix_dist--;
+                }
+                glz_close_copy(o, copy, lane);
+                copy = 0;
+                glz_put_match(o, image_dist, pix_dist, (uint32_t)(len - T::LEN_BIAS), lane);
+                {
+                    const int p0 = anchor + len - 2, p1 = p0 + 1;
+                    const bool ins0 = !T::GUARD_A || p0 > anchor;
+                    const bool ins1 = !T::GUARD_B || p1 > anchor;
+                    const int w0i = p0 - ip, w1i = p1 - ip;
+                    uint32_t h0, h1;
+                    if (w1i < GLZ_WIN) {
+                        /* step 1 hashed every window position whose three pixels exist */
+                        h0 = sh.info[w0i].h;
+                        h1 = sh.info[w1i].h;
+                    } else {
+                        h0 = glz_hash_at<MODE>(base, p0);
+                        h1 = glz_hash_at<MODE>(base, p1);
+                    }
+                    if (lane == 0) {
+                        if (ins0) {
+                            job.htab[h0] = make_uint2(seg_idx, (uint32_t)p0);
+                        }
+                        if (ins1) {
+                            job.htab[h1] = make_uint2(seg_idx, (uint32_t)p1);
+                        }
+                    }
+                    if (w0i < GLZ_WIN && ins0) {
+                        glz_mask_set(inserted, w0i);
+                    }
+                    if (w1i < GLZ_WIN && ins1) {
+                        glz_mask_set(inserted, w1i);
                     }
                 }
-                if (p0 - ip < 64 && ins0) {
-                    inserted |= 1ull << (p0 - ip);
-                }
-                if (p1 - ip < 64 && ins1) {
-                    inserted |= 1ull << (p1 - ip);
-                }
+                glz_put_copy_count(o, GLZ_MAX_COPY - 1, lane);
+                i += len;
             }
-            glz_put_copy_count(o, GLZ_MAX_COPY - 1, lane);
-            i += len;
+            glz_flush_literals<MODE>(o, copy, lit, sh.tile, lane);
+            if (lane == 0) {
+                sh.next_ip = ip + i; /* i counts every pixel consumed, also past the window */
+            }
         }
-        glz_flush_literals<MODE>(o, copy, lit_mask, raw0, lane);
-        ip += i; /* i counts every pixel consumed, including a match that ran past the window */
+        __syncthreads();
+        ip = sh.next_ip;
+        __syncthreads();
     }
 
     /* ---- leftovers as literals, glz_encode_tmpl.c:466-487 */
-    {
-        const int left = npix - ip; /* positions ip .. npix-1 */
-        uint32_t raw = 0;
-        uint64_t mask = 0;
-        if (left > 0) {
-            if (lane < left) {
-                raw = glz_load_px<MODE>(base, ip + lane);
-            }
-            mask = left >= 64 ? ~0ull : ((1ull << left) - 1);
-        }
-        glz_flush_literals<MODE>(o, copy, mask, raw, lane);
+    if (w0) {
+        glz_literals_from_arena<MODE>(o, copy, base, ip, npix - ip, sh.tile, lane);
         glz_close_copy(o, copy, lane);
     }
+    __syncthreads();
 }
 
 /* glz_encode_tmpl.c:498-555 */
 template <int MODE>
-__device__ void glz_parse_image(const GlzDevJob &job, const uint32_t *seg_list, GlzOut &o, int lane)
+__device__ __forceinline__ void glz_parse_image(const GlzDevJob &job, const uint32_t *seg_list,
+                                                GlzOut &o, int tid)
 {
-    typedef GlzTraits<MODE> T;
+    GlzShared &sh = glz_sh;
+    const int lane = tid & 63;
+    const bool w0 = tid < GLZ_WAVE;
     uint32_t s = 0;
 
     /* segments shorter than 4 pixels are copied verbatim */
     for (; s < job.nsegs; s++) {
-        const GlzDevSeg cs = job.segs[seg_list[s]];
+        const GlzDevSeg cs = glz_seg(job, sh, seg_list[s]);
         if (cs.nunits >= 4) {
             break;
         }
-        if (cs.nunits > 0) {
+        if (cs.nunits > 0 && w0) {
             const uint8_t *base = job.arena + (size_t)cs.arena_off16 * 16;
             int copy = 0;
-            uint32_t raw = 0;
             glz_put_copy_count(o, cs.nunits - 1, lane);
-            if (lane < (int)cs.nunits) {
-                raw = glz_load_px<MODE>(base, lane);
-            }
-            glz_flush_literals<MODE>(o, copy, (1ull << cs.nunits) - 1, raw, lane);
+            glz_literals_from_arena<MODE>(o, copy, base, 0, (int)cs.nunits, sh.tile, lane);
         }
     }
-    if (s == job.nsegs) {
-        return;
-    }
-    {
+    bool first = true;
+    for (; s < job.nsegs; s++) {
         const uint32_t sid = seg_list[s];
-        const GlzDevSeg cs = job.segs[sid];
-        const uint8_t *base = job.arena + (size_t)cs.arena_off16 * 16;
-        int copy = 0;
-        uint32_t raw = 0;
-        glz_put_copy_count(o, GLZ_MAX_COPY - 1, lane);
-        if (lane == 0) {
-            job.htab[glz_hash_at<MODE>(base, 0)] = make_uint2(sid, 0);
+        if (first) {
+            /* the first real segment starts with a hash insert and two literals */
+            if (w0) {
+                const GlzDevSeg cs = glz_seg(job, sh, sid);
+                const uint8_t *base = job.arena + (size_t)cs.arena_off16 * 16;
+                int copy = 0;
+                glz_put_copy_count(o, GLZ_MAX_COPY - 1, lane);
+                if (lane == 0) {
+                    job.htab[glz_hash_at<MODE>(base, 0)] = make_uint2(sid, 0);
+                }
+                glz_literals_from_arena<MODE>(o, copy, base, 0, 2, sh.tile, lane);
+            }
+            __syncthreads();
         }
-        if (lane < 2) {
-            raw = glz_load_px<MODE>(base, lane);
-        }
-        glz_flush_literals<MODE>(o, copy, 3ull, raw, lane);
-        glz_parse_seg<MODE>(job, sid, 2, 2, o, lane);
+        glz_parse_seg<MODE>(job, sid, first ? 2 : 0, first ? 2 : 0, o, tid);
+        first = false;
     }
-    for (s++; s < job.nsegs; s++) {
-        glz_parse_seg<MODE>(job, seg_list[s], 0, 0, o, lane);
-    }
-    (void)sizeof(T);
 }
 
-/* One wavefront per job: apply the window-table updates, write the header
+/* One workgroup per job: apply the window-table updates, write the header
  * (glz_encoder.c:264-276), parse, report the size. */
-__global__ void __launch_bounds__(GLZ_WAVE)
-glz_parse_kernel(const GlzDevJob *jobs, const uint32_t *u32_pool, const GlzDevSegUpdate *upd_pool)
+template <int TYPE>
+__global__ void __launch_bounds__(GLZ_THREADS)
+glz_parse_kernel(const GlzDevJob *__restrict__ jobs, const uint32_t *__restrict__ u32_pool,
+                 const GlzDevSegUpdate *__restrict__ upd_pool)
 {
+    GlzShared &sh = glz_sh;
     const GlzDevJob job = jobs[blockIdx.x];
-    const int lane = (int)threadIdx.x;
+    if ((int)job.type != TYPE) {
+        return; /* another instantiation of this kernel handles that pixel type */
+    }
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63;
 
-    for (uint32_t u = (uint32_t)lane; u < job.nupd; u += GLZ_WAVE) {
+    for (uint32_t u = (uint32_t)tid; u < job.nupd; u += GLZ_THREADS) {
         const GlzDevSegUpdate up = upd_pool[job.upd_off + u];
         job.segs[up.index] = up.seg;
+    }
+    __syncthreads();
+    if (tid < GLZ_SEG_CACHE) {
+        sh.seg_cache[tid] = job.segs[tid];
     }
     __syncthreads();
 
@@ -596,7 +812,7 @@ glz_parse_kernel(const GlzDevJob *jobs, const uint32_t *u32_pool, const GlzDevSe
     o.last_copy = 0;
     o.high = 0;
 
-    if (lane < GLZ_HEADER_BYTES) {
+    if (tid < GLZ_HEADER_BYTES) {
         uint32_t b;
         const uint32_t id_hi = (uint32_t)(job.image_id >> 32);
         const uint32_t id_lo = (uint32_t)(job.image_id & 0xffffffu); /* glz_encoder.c:86 */
@@ -624,27 +840,19 @@ glz_parse_kernel(const GlzDevJob *jobs, const uint32_t *u32_pool, const GlzDevSe
     glz_advance(o, GLZ_HEADER_BYTES);
 
     const uint32_t *seg_list = u32_pool + job.seg_list_off;
-    int err = 0;
-    switch (job.type) {
-    case 6:
-        glz_parse_image<GLZ_MODE_RGB16>(job, seg_list, o, lane);
-        break;
-    case 7:
-        glz_parse_image<GLZ_MODE_RGB24>(job, seg_list, o, lane);
-        break;
-    case 8:
-        glz_parse_image<GLZ_MODE_RGB32>(job, seg_list, o, lane);
-        break;
-    case 9:
-        glz_parse_image<GLZ_MODE_RGB32>(job, seg_list, o, lane);
-        glz_parse_image<GLZ_MODE_ALPHA>(job, seg_list, o, lane);
-        break;
-    default:
-        err = GLZ_DEV_ERR_BAD_TYPE;
-        break;
+    if (TYPE == 6) {
+        glz_parse_image<GLZ_MODE_RGB16>(job, seg_list, o, tid);
+    } else if (TYPE == 7) {
+        glz_parse_image<GLZ_MODE_RGB24>(job, seg_list, o, tid);
+    } else {
+        glz_parse_image<GLZ_MODE_RGB32>(job, seg_list, o, tid);
+        if (TYPE == 9) {
+            __syncthreads();
+            glz_parse_image<GLZ_MODE_ALPHA>(job, seg_list, o, tid);
+        }
     }
-    if (lane == 0) {
-        *job.result = err ? err : (o.high > o.cap ? GLZ_DEV_ERR_NO_SPACE : (int32_t)o.op);
+    if (tid == 0) {
+        *job.result = o.high > o.cap ? GLZ_DEV_ERR_NO_SPACE : (int32_t)o.op;
     }
 }
 
@@ -672,12 +880,24 @@ glz_copy_kernel(const GlzCopyDesc *descs)
     }
 }
 
-void glz_launch_parse(const GlzDevJob *jobs, int njobs, const uint32_t *u32_pool,
+/* type_mask: bit t set when some job has LzImageType t (6..9) */
+void glz_launch_parse(const GlzDevJob *jobs, int njobs, unsigned type_mask, const uint32_t *u32_pool,
                       const GlzDevSegUpdate *upd_pool, hipStream_t stream)
 {
+    const dim3 grid((unsigned)njobs), block(GLZ_THREADS);
     const int t = spicegpu::timing_begin("glz_parse_kernel", stream);
-    hipLaunchKernelGGL(glz_parse_kernel, dim3((unsigned)njobs), dim3(GLZ_WAVE), 0, stream, jobs,
-                       u32_pool, upd_pool);
+    if (type_mask & (1u << 8)) {
+        hipLaunchKernelGGL(glz_parse_kernel<8>, grid, block, 0, stream, jobs, u32_pool, upd_pool);
+    }
+    if (type_mask & (1u << 9)) {
+        hipLaunchKernelGGL(glz_parse_kernel<9>, grid, block, 0, stream, jobs, u32_pool, upd_pool);
+    }
+    if (type_mask & (1u << 7)) {
+        hipLaunchKernelGGL(glz_parse_kernel<7>, grid, block, 0, stream, jobs, u32_pool, upd_pool);
+    }
+    if (type_mask & (1u << 6)) {
+        hipLaunchKernelGGL(glz_parse_kernel<6>, grid, block, 0, stream, jobs, u32_pool, upd_pool);
+    }
     spicegpu::timing_end(t, stream);
 }
 
