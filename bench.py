@@ -49,53 +49,7 @@ def parse_args():
     return ap.parse_args()
 
 
-class Dist:
-    """Barrier / max / gather over the ranks; trivial for one process."""
-
-    def __init__(self):
-        self.rank = int(os.environ.get("RANK", "0"))
-        self.world = int(os.environ.get("WORLD_SIZE", "1"))
-        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-        import torch
-        self.torch = torch
-        torch.cuda.set_device(self.local_rank)
-        self.dev = torch.device("cuda", self.local_rank)
-        if self.world > 1:
-            import torch.distributed as dist
-            self.dist = dist
-            dist.init_process_group(backend="nccl", device_id=self.dev)
-
-    def barrier(self):
-        if self.world > 1:
-            self.dist.barrier()
-        self.torch.cuda.synchronize()
-
-    def max(self, v):
-        if self.world == 1:
-            return v
-        t = self.torch.tensor([v], dtype=self.torch.float64, device=self.dev)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        return float(t.item())
-
-    def sum(self, v):
-        if self.world == 1:
-            return v
-        t = self.torch.tensor([v], dtype=self.torch.float64, device=self.dev)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        return float(t.item())
-
-    def gather_i64(self, values):
-        """all_gather of a small int64 vector (the stat_info_t-shaped counters)."""
-        if self.world == 1:
-            return [list(values)]
-        t = self.torch.tensor(values, dtype=self.torch.int64, device=self.dev)
-        outs = [self.torch.empty_like(t) for _ in range(self.world)]
-        self.dist.all_gather(outs, t)
-        return [o.tolist() for o in outs]
-
-    def close(self):
-        if self.world > 1:
-            self.dist.destroy_process_group()
+from spice_amd.sharding import Dist  # noqa: E402
 
 
 # ----------------------------------------------------------------------- GLZ
