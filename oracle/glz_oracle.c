@@ -92,6 +92,29 @@ typedef struct OEnc {
     int overflow;
 } OEnc;
 
+/* Optional trace of the parser's stops (seg-relative anchor, length; 0 = literal,
+ * bit 31 = run).  Analysis aid for tests; not thread safe. */
+static uint32_t *g_trace;
+static size_t g_trace_cap, g_trace_n;
+void glzo_set_trace(uint32_t *buf, size_t cap_pairs)
+{
+    g_trace = buf;
+    g_trace_cap = cap_pairs;
+    g_trace_n = 0;
+}
+size_t glzo_trace_count(void)
+{
+    return g_trace_n;
+}
+#define TRACE(a, l)                                                    \
+    do {                                                               \
+        if (g_trace && g_trace_n < g_trace_cap) {                      \
+            g_trace[2 * g_trace_n] = (uint32_t)(a);                    \
+            g_trace[2 * g_trace_n + 1] = (uint32_t)(l);                \
+            g_trace_n++;                                               \
+        }                                                              \
+    } while (0)
+
 /* ---------------------------------------------------------------- byte sink
  * glz_encoder.c:62-108.  The reference writes into a chain of buffers; the
  * stream it produces is the same as one linear buffer. */

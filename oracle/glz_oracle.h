@@ -89,6 +89,11 @@ void glzo_remove_image(GlzoDict *d, void *image);
 int glzo_pop_freed(GlzoDict *d, uint64_t *tags, int max);
 void glzo_get_stats(GlzoDict *d, GlzoStats *out, int reset);
 
+/* Record every parser stop as a pair (position in its segment, length:
+ * 0 literal, bit 31 run, bit 30 match into another image).  Process-wide. */
+void glzo_set_trace(uint32_t *buf, size_t cap_pairs);
+size_t glzo_trace_count(void);
+
 GlzoDecWindow *glzo_decwin_create(void);
 void glzo_decwin_destroy(GlzoDecWindow *w);
 /* Decodes one GLZ stream to its own pixel type.  Returns bytes consumed from

@@ -1,5 +1,5 @@
 import sys, time, numpy as np
-sys.path.insert(0,'.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import spice_amd
 from spice_amd import binding as B, frames
 gpu=spice_amd.load(0)

@@ -5,24 +5,27 @@
  * The reference parser (server/glz_encode_tmpl.c:268-491) is a strictly serial
  * walk: at every "stop" it probes a single-slot hash table whose contents
  * depend on all earlier stops.  This kernel keeps that order -- the output is
- * byte-identical -- but evaluates GLZ_WIN consecutive positions per step:
+ * byte-identical -- but splits the work on a window of GLZ_WIN consecutive
+ * positions into three phases:
  *
- *   1. gather (all four wavefronts): every lane takes one position of the
- *      window [ip, ip+256): run test, 3-pixel hash, hash-table probe, reference
- *      validation (REF_SEG_IS_VALID, glz_encoder_dictionary_protected.h:176-184),
- *      do_match's distance rules (glz_encode_tmpl.c:147-229) and the first
- *      GLZ_K pixels of the match extension, all as parallel gathers from HBM;
- *      the window's own pixels are staged in LDS;
- *   2. resolve (wavefront 0): visits the real stops in order out of LDS.  A
- *      probe answered in step 1 is still the truth unless a stop *inside the
- *      window* stored the same hash since; ballots over the window's hashes
- *      find that case, and the compare then runs on the LDS tile;
- *   3. matches that outgrow step 1 (the few long ones that cover most pixels)
- *      are extended 512 pixels per iteration; literal and match bytes are
- *      written cooperatively.
- *
- * Hash-table stores are issued by lane 0 only, in stop order, so that memory
- * sees them in the order the reference performs them.
+ *   scan (all four wavefronts, one position per lane): run test, 3-pixel hash,
+ *      hash-table probe with reference validation (REF_SEG_IS_VALID,
+ *      glz_encoder_dictionary_protected.h:176-184) and do_match's rules
+ *      (glz_encode_tmpl.c:147-262) for the slot's content as it was when the
+ *      window was entered, and the same for the two nearest earlier window
+ *      positions with the same hash (found through an LDS bitmap keyed by the
+ *      hash's low bits).  Every candidate is compared over its first GLZ_K
+ *      pixels and the accept / reject decision is taken here;
+ *   resolve (wavefront 0): visits the real stops in order.  The table slot a
+ *      stop sees is the most recent store to it: the nearest earlier window
+ *      position with that hash that really was a store (a stop or one of the
+ *      two positions stored after a match), else what the scan read.  Per stop
+ *      this is a handful of register reads; only candidates that outgrow
+ *      GLZ_K pixels, or whose two nearest predecessors were both skipped, fall
+ *      back to wave-wide compares;
+ *   emit (all four wavefronts): sizes of the window's literals and matches are
+ *      prefix-summed and every lane writes its own token; the window's table
+ *      stores are issued here too, one per slot (the last store wins).
  */
 #include <hip/hip_runtime.h>
 
@@ -32,25 +35,47 @@
 #define GLZ_WAVE 64
 #define GLZ_THREADS 256
 #define GLZ_WIN 256                       /* window positions per step */
-#define GLZ_K 8                           /* pixels every lane pre-compares against its candidate */
+#define GLZ_K 16                          /* pixels every lane pre-compares against a candidate */
 #define GLZ_TILE (GLZ_WIN + GLZ_K + 4)    /* LDS pixels: positions ip-1 .. ip+WIN+K+2 */
 #define GLZ_SEG_CACHE 64                  /* segment slots mirrored in LDS */
-#define GLZ_UNROLL 8                      /* 64-pixel rows per iteration of the long compares */
+#define GLZ_KEYS 256                      /* rows of the same-hash bitmap */
+#define GLZ_NO_HASH 0xffffffffu
 
-#define GLZ_F_ACT 1u
-#define GLZ_F_RLE 2u
-#define GLZ_F_GOK 4u
-#define GLZ_F_MAXED 8u
+/* first scan word of a position */
+#define GLZ_A_ACT 0x1u                    /* a stop may happen here (before ip_limit) */
+#define GLZ_A_RLE 0x2u                    /* the run test succeeds */
+#define GLZ_A_P1V 0x8u                    /* an earlier window position has the same hash */
+#define GLZ_A_P2V 0x10u                   /* ... and a second one */
+#define GLZ_A_P1_SHIFT 5                  /* 8 bits: nearest such position */
+#define GLZ_A_LEN1_SHIFT 13               /* 5 bits: accepted length against it (0 = rejected) */
+#define GLZ_A_MAX1 0x40000u               /* ... compare stopped at GLZ_K, not at a difference */
+#define GLZ_A_GLEN_SHIFT 19               /* 5 bits: accepted length against the table's entry */
+#define GLZ_A_GMAX 0x1000000u
+#define GLZ_A_P1SAME 0x2000000u           /* that position lies in the same quarter (64 positions) */
+#define GLZ_A_P2SAME 0x4000000u
+#define GLZ_A_MORE 0x8000000u             /* a third earlier window position has the same hash */
+/* second scan word */
+#define GLZ_B_LEN2_SHIFT 8
+#define GLZ_B_MAX2 0x2000u
 
-/* what step 1 leaves in LDS for each window position */
-struct GlzPosInfo {
-    uint32_t h;
-    uint32_t flags;    /* GLZ_F_* | pre-compared length << 8 */
-    uint32_t g_ref;
-    uint32_t g_seg;
-    uint32_t g_image_dist;
-    uint32_t g_pix_dist;
-};
+/* where a match came from (top three bits of a token) */
+#define GLZ_SEL_P1 0u
+#define GLZ_SEL_P2 1u
+#define GLZ_SEL_TABLE 2u
+#define GLZ_SEL_RUN 3u
+#define GLZ_SEL_DEEP 4u
+#define GLZ_TOK_LEN_MASK 0x1fffffffu
+
+/* Pointers that arrive inside the job record are generic to the compiler; the
+ * kernel retypes them as global memory so that loads through them are plain
+ * global loads and values read at a wave-uniform address stay wave-uniform. */
+#ifdef SPICE_WAVE_SIM
+#define GLZ_GLOBAL
+#else
+#define GLZ_GLOBAL __attribute__((address_space(1)))
+#endif
+typedef uint32_t glz_u32x4 __attribute__((vector_size(16)));
+typedef glz_u32x4 glz_u32x4_u __attribute__((aligned(4))); /* pixel-aligned only */
 
 enum { GLZ_MODE_RGB32 = 0, GLZ_MODE_RGB24 = 1, GLZ_MODE_RGB16 = 2, GLZ_MODE_ALPHA = 3 };
 
@@ -79,15 +104,15 @@ template <> struct GlzTraits<GLZ_MODE_ALPHA> {
 
 /* raw value of pixel idx: b|g<<8|r<<16(|pad<<24), the 16-bit word, or the pad byte */
 template <int MODE>
-__device__ __forceinline__ uint32_t glz_load_px(const uint8_t *base, int idx)
+__device__ __forceinline__ uint32_t glz_load_px(const GLZ_GLOBAL uint8_t *base, int idx)
 {
     if (MODE == GLZ_MODE_RGB32) {
-        return ((const uint32_t *)base)[idx];
+        return ((const GLZ_GLOBAL uint32_t *)base)[idx];
     } else if (MODE == GLZ_MODE_RGB24) {
-        const uint8_t *p = base + (size_t)idx * 3;
+        const GLZ_GLOBAL uint8_t *p = base + (size_t)idx * 3;
         return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
     } else if (MODE == GLZ_MODE_RGB16) {
-        return ((const uint16_t *)base)[idx];
+        return ((const GLZ_GLOBAL uint16_t *)base)[idx];
     } else {
         return base[(size_t)idx * 4 + 3];
     }
@@ -114,47 +139,25 @@ __device__ __forceinline__ uint32_t glz_hash3(uint32_t a, uint32_t b, uint32_t c
     return h & GLZ_HASH_MASK;
 }
 
-/* Wave-uniform output cursor.  Every lane holds the same copy. */
-struct GlzOut {
-    uint8_t *buf;
-    uint32_t cap;
-    uint32_t op;        /* next byte */
-    uint32_t last_copy; /* position of the most recent copy-count byte */
-    uint32_t high;      /* furthest position ever reached (overflow detection) */
-};
-
-__device__ __forceinline__ void glz_put(GlzOut &o, uint32_t pos, uint32_t b)
+__device__ __forceinline__ void glz_put(GLZ_GLOBAL uint8_t *buf, uint32_t cap, uint32_t pos, uint32_t b)
 {
-    if (pos < o.cap) {
-        o.buf[pos] = (uint8_t)b;
+    if (pos < cap) {
+        buf[pos] = (uint8_t)b;
     }
 }
 
-__device__ __forceinline__ void glz_advance(GlzOut &o, uint32_t n)
+template <int MODE>
+__device__ __forceinline__ void glz_put_pixel(GLZ_GLOBAL uint8_t *buf, uint32_t cap, uint32_t pos, uint32_t raw)
 {
-    o.op += n;
-    o.high = o.op > o.high ? o.op : o.high;
-}
-
-/* glz_encoder.c:89-93 */
-__device__ __forceinline__ void glz_put_copy_count(GlzOut &o, uint32_t v, int lane)
-{
-    if (lane == 0) {
-        glz_put(o, o.op, v);
-    }
-    o.last_copy = o.op;
-    glz_advance(o, 1);
-}
-
-/* glz_encoder.c:95-108: close the literal run that precedes a match / the end */
-__device__ __forceinline__ void glz_close_copy(GlzOut &o, int copy, int lane)
-{
-    if (copy) {
-        if (lane == 0) {
-            glz_put(o, o.last_copy, (uint32_t)(copy - 1));
-        }
+    if (MODE == GLZ_MODE_RGB32 || MODE == GLZ_MODE_RGB24) {
+        glz_put(buf, cap, pos, raw & 0xff);
+        glz_put(buf, cap, pos + 1, (raw >> 8) & 0xff);
+        glz_put(buf, cap, pos + 2, (raw >> 16) & 0xff);
+    } else if (MODE == GLZ_MODE_RGB16) {
+        glz_put(buf, cap, pos, (raw >> 8) & 0xff);
+        glz_put(buf, cap, pos + 1, raw & 0xff);
     } else {
-        o.op--;
+        glz_put(buf, cap, pos, raw & 0xff);
     }
 }
 
@@ -173,256 +176,275 @@ __device__ __forceinline__ int glz_ref_bytes(uint32_t image_dist, uint32_t pix_d
     return n;
 }
 
-/* glz_encode_match_tmpl.c:31-151, emission part.  len is already biased. */
-__device__ void glz_put_match(GlzOut &o, uint32_t image_dist, uint32_t pix_dist, uint32_t len,
-                              int lane)
+/* glz_encode_match_tmpl.c:31-151: bytes of one match; len is already biased */
+__device__ __forceinline__ uint32_t glz_match_bytes(uint32_t image_dist, uint32_t pix_dist, uint32_t len)
+{
+    const uint32_t nlen = len < 7 ? 1u : 2u + (len - 7) / 255u;
+    return nlen + (uint32_t)glz_ref_bytes(image_dist, pix_dist) - 1;
+}
+
+/* glz_encode_match_tmpl.c:31-151, written by one lane.  The 0xff bytes of a
+ * long length are left to the caller when there are more than max_ff of them. */
+__device__ __forceinline__ void glz_write_match(GLZ_GLOBAL uint8_t *buf, uint32_t cap, uint32_t pos,
+                                                uint32_t image_dist, uint32_t pix_dist,
+                                                uint32_t len, uint32_t max_ff)
 {
     const uint32_t far_px = pix_dist >= 4096u;
     const uint32_t low = (far_px ? 16u : 0u) + (pix_dist & 0x0f);
-    uint32_t pos = o.op;
-    uint32_t n = 0; /* bytes, counted identically by every lane */
+    uint32_t p = pos;
 
     if (len < 7) {
-        if (lane == 0) {
-            glz_put(o, pos, (len << 5) + low);
-        }
-        n = 1;
+        glz_put(buf, cap, p++, (len << 5) + low);
     } else {
-        uint32_t rem = len - 7, nff = rem / 255u, last = rem - nff * 255u;
-        if (lane == 0) {
-            glz_put(o, pos, (7u << 5) + low);
-            glz_put(o, pos + 1 + nff, last);
-        }
-        for (uint32_t t = (uint32_t)lane; t < nff; t += GLZ_WAVE) {
-            glz_put(o, pos + 1 + t, 255u);
-        }
-        n = 2 + nff;
-    }
-    if (lane == 0) {
-        uint32_t p = pos + n;
-        glz_put(o, p++, (pix_dist >> 4) & 255u);
-        if (!far_px) {
-            if (image_dist < (1u << 6)) {
-                glz_put(o, p++, image_dist & 0x3f);
-            } else if (image_dist < (1u << 14)) {
-                glz_put(o, p++, (1u << 6) + (image_dist & 0x3f));
-                glz_put(o, p++, (image_dist >> 6) & 255u);
-            } else if (image_dist < (1u << 22)) {
-                glz_put(o, p++, (1u << 7) + (image_dist & 0x3f));
-                glz_put(o, p++, (image_dist >> 6) & 255u);
-                glz_put(o, p++, (image_dist >> 14) & 255u);
-            } else {
-                glz_put(o, p++, (1u << 7) + (1u << 6) + (image_dist & 0x3f));
-                glz_put(o, p++, (image_dist >> 6) & 255u);
-                glz_put(o, p++, (image_dist >> 14) & 255u);
-                glz_put(o, p++, (image_dist >> 22) & 255u);
+        const uint32_t rem = len - 7, nff = rem / 255u, last = rem - nff * 255u;
+        glz_put(buf, cap, p++, (7u << 5) + low);
+        if (nff <= max_ff) {
+            for (uint32_t t = 0; t < nff; t++) {
+                glz_put(buf, cap, p + t, 255u);
             }
+        }
+        p += nff;
+        glz_put(buf, cap, p++, last);
+    }
+    glz_put(buf, cap, p++, (pix_dist >> 4) & 255u);
+    if (!far_px) {
+        if (image_dist < (1u << 6)) {
+            glz_put(buf, cap, p++, image_dist & 0x3f);
+        } else if (image_dist < (1u << 14)) {
+            glz_put(buf, cap, p++, (1u << 6) + (image_dist & 0x3f));
+            glz_put(buf, cap, p++, (image_dist >> 6) & 255u);
+        } else if (image_dist < (1u << 22)) {
+            glz_put(buf, cap, p++, (1u << 7) + (image_dist & 0x3f));
+            glz_put(buf, cap, p++, (image_dist >> 6) & 255u);
+            glz_put(buf, cap, p++, (image_dist >> 14) & 255u);
         } else {
-            uint32_t very_far = pix_dist < 131072u ? 0u : 32u;
-            uint32_t hi = (pix_dist >> 12) & 31u;
-            if (image_dist == 0) {
-                glz_put(o, p++, very_far + hi);
-            } else if (image_dist < (1u << 8)) {
-                glz_put(o, p++, very_far + (1u << 6) + hi);
-                glz_put(o, p++, image_dist & 255u);
-            } else if (image_dist < (1u << 16)) {
-                glz_put(o, p++, very_far + (1u << 7) + hi);
-                glz_put(o, p++, image_dist & 255u);
-                glz_put(o, p++, (image_dist >> 8) & 255u);
-            } else {
-                glz_put(o, p++, very_far + (1u << 7) + (1u << 6) + hi);
-                glz_put(o, p++, image_dist & 255u);
-                glz_put(o, p++, (image_dist >> 8) & 255u);
-                glz_put(o, p++, (image_dist >> 16) & 255u);
-            }
-            if (very_far) {
-                glz_put(o, p++, (pix_dist >> 17) & 255u);
-            }
+            glz_put(buf, cap, p++, (1u << 7) + (1u << 6) + (image_dist & 0x3f));
+            glz_put(buf, cap, p++, (image_dist >> 6) & 255u);
+            glz_put(buf, cap, p++, (image_dist >> 14) & 255u);
+            glz_put(buf, cap, p++, (image_dist >> 22) & 255u);
+        }
+    } else {
+        const uint32_t very_far = pix_dist < 131072u ? 0u : 32u;
+        const uint32_t hi = (pix_dist >> 12) & 31u;
+        if (image_dist == 0) {
+            glz_put(buf, cap, p++, very_far + hi);
+        } else if (image_dist < (1u << 8)) {
+            glz_put(buf, cap, p++, very_far + (1u << 6) + hi);
+            glz_put(buf, cap, p++, image_dist & 255u);
+        } else if (image_dist < (1u << 16)) {
+            glz_put(buf, cap, p++, very_far + (1u << 7) + hi);
+            glz_put(buf, cap, p++, image_dist & 255u);
+            glz_put(buf, cap, p++, (image_dist >> 8) & 255u);
+        } else {
+            glz_put(buf, cap, p++, very_far + (1u << 7) + (1u << 6) + hi);
+            glz_put(buf, cap, p++, image_dist & 255u);
+            glz_put(buf, cap, p++, (image_dist >> 8) & 255u);
+            glz_put(buf, cap, p++, (image_dist >> 16) & 255u);
+        }
+        if (very_far) {
+            glz_put(buf, cap, p++, (pix_dist >> 17) & 255u);
         }
     }
-    /* 1 distance byte + the image-distance bytes */
-    n += (uint32_t)glz_ref_bytes(image_dist, pix_dist) - 1;
-    glz_advance(o, n);
 }
 
-/* 256-bit window masks as four words, touched only through compile-time
- * indices so that they stay in registers */
-struct GlzMask {
-    uint64_t w0, w1, w2, w3;
-};
-__device__ __forceinline__ bool glz_mask_test(const GlzMask &m, int i)
+__device__ __forceinline__ uint32_t glz_readlane(uint32_t v, int lane)
 {
-    const int w = i >> 6;
-    const uint64_t v = w == 0 ? m.w0 : (w == 1 ? m.w1 : (w == 2 ? m.w2 : m.w3));
-    return (v >> (i & 63)) & 1;
-}
-__device__ __forceinline__ void glz_mask_set(GlzMask &m, int i)
-{
-    const int w = i >> 6;
-    const uint64_t b = 1ull << (i & 63);
-    m.w0 |= w == 0 ? b : 0;
-    m.w1 |= w == 1 ? b : 0;
-    m.w2 |= w == 2 ? b : 0;
-    m.w3 |= w == 3 ? b : 0;
-}
-__device__ __forceinline__ void glz_mask_clear(GlzMask &m)
-{
-    m.w0 = m.w1 = m.w2 = m.w3 = 0;
-}
-/* bits of m strictly below position i */
-__device__ __forceinline__ GlzMask glz_mask_below(const GlzMask &m, int i)
-{
-    const int w = i >> 6;
-    const uint64_t part = (1ull << (i & 63)) - 1;
-    GlzMask r;
-    r.w0 = w > 0 ? m.w0 : (m.w0 & part);
-    r.w1 = w > 1 ? m.w1 : (w == 1 ? (m.w1 & part) : 0);
-    r.w2 = w > 2 ? m.w2 : (w == 2 ? (m.w2 & part) : 0);
-    r.w3 = w == 3 ? (m.w3 & part) : 0;
-    return r;
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
 }
 
-/* Literal pixels of the window positions in mask[] (bit p of word p/64), in
- * order, with the copy-count bytes that fall between them
- * (glz_encode_tmpl.c:449-462).  Wavefront 0 only; pixels come from the LDS tile. */
+/* a value every lane of the wavefront holds, moved to where the compiler knows it */
+__device__ __forceinline__ uint32_t glz_uniform(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+
+__device__ __forceinline__ uint64_t glz_uniform64(uint64_t v)
+{
+    return (uint64_t)glz_uniform((uint32_t)v) | ((uint64_t)glz_uniform((uint32_t)(v >> 32)) << 32);
+}
+
+#define GLZ_ROWS 4 /* rows of 256 (4-byte pixels) or 64 (others) per iteration of the long compares */
+
+/* the bits of a raw 4-byte pixel that take part in comparisons */
 template <int MODE>
-__device__ __forceinline__ void glz_flush_literals(GlzOut &o, int &copy, const GlzMask &lit,
-                                                   const uint32_t *tile, int lane)
+__device__ __forceinline__ uint32_t glz_raw_mask()
 {
-    typedef GlzTraits<MODE> T;
-    const uint64_t mask[4] = {lit.w0, lit.w1, lit.w2, lit.w3};
-    const int n0 = __popcll(mask[0]), n1 = __popcll(mask[1]), n2 = __popcll(mask[2]);
-    const int n = n0 + n1 + n2 + __popcll(mask[3]);
-    if (n == 0) {
-        return;
-    }
-    const int total_ctrl = (copy + n) >> 5;
-    int before = 0;
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-        if ((mask[w] >> lane) & 1) {
-            const int k = before + __popcll(mask[w] & ((1ull << lane) - 1));
-            const uint32_t raw = tile[w * 64 + lane + 1];
-            const uint32_t pos = o.op + (uint32_t)k * T::LITB + (uint32_t)((copy + k) >> 5);
-            if (MODE == GLZ_MODE_RGB32 || MODE == GLZ_MODE_RGB24) {
-                glz_put(o, pos, raw & 0xff);
-                glz_put(o, pos + 1, (raw >> 8) & 0xff);
-                glz_put(o, pos + 2, (raw >> 16) & 0xff);
-            } else if (MODE == GLZ_MODE_RGB16) {
-                glz_put(o, pos, (raw >> 8) & 0xff);
-                glz_put(o, pos + 1, raw & 0xff);
-            } else {
-                glz_put(o, pos, raw & 0xff);
-            }
-            /* a full run of 32 is followed by the next run's count byte; the last
-             * one of this flush may still be patched, so lane 0 owns it (below) */
-            if (((copy + k + 1) & 31) == 0 && ((copy + k + 1) >> 5) < total_ctrl) {
-                glz_put(o, pos + T::LITB, GLZ_MAX_COPY - 1);
-            }
-        }
-        before += w == 0 ? n0 : (w == 1 ? n1 : n2);
-    }
-    if (total_ctrl) {
-        const int kk = 32 * total_ctrl - copy - 1; /* literal after which the last count byte sits */
-        o.last_copy = o.op + (uint32_t)kk * T::LITB + (uint32_t)((copy + kk) >> 5) + T::LITB;
-        if (lane == 0) {
-            glz_put(o, o.last_copy, GLZ_MAX_COPY - 1);
-        }
-    }
-    glz_advance(o, (uint32_t)n * T::LITB + (uint32_t)total_ctrl);
-    copy = (copy + n) & 31;
+    return MODE == GLZ_MODE_ALPHA ? 0xff000000u : 0x00ffffffu;
 }
 
-/* Up to 64 literal pixels straight from the window arena (segment heads and
- * tails), glz_encode_tmpl.c:466-487,511-541.  Wavefront 0 only. */
-template <int MODE>
-__device__ __forceinline__ void glz_literals_from_arena(GlzOut &o, int &copy, const uint8_t *base,
-                                                        int first, int count, uint32_t *scratch,
-                                                        int lane)
+/* leading pixels (0..4) on which two groups of four raw pixels agree */
+__device__ __forceinline__ int glz_agree4(const glz_u32x4 a, const glz_u32x4 b, uint32_t mask)
 {
-    if (count <= 0) {
-        return;
-    }
-    /* reuse the tile layout expected by glz_flush_literals: pixel p at scratch[p + 1] */
-    if (lane < count) {
-        scratch[lane + 1] = glz_load_px<MODE>(base, first + lane);
-    }
-    GlzMask mask;
-    glz_mask_clear(mask);
-    mask.w0 = count >= 64 ? ~0ull : ((1ull << count) - 1);
-    glz_flush_literals<MODE>(o, copy, mask, scratch, lane);
+    const bool e0 = ((a[0] ^ b[0]) & mask) == 0, e1 = ((a[1] ^ b[1]) & mask) == 0;
+    const bool e2 = ((a[2] ^ b[2]) & mask) == 0, e3 = ((a[3] ^ b[3]) & mask) == 0;
+    return !e0 ? 0 : (!e1 ? 1 : (!e2 ? 2 : (!e3 ? 3 : 4)));
 }
 
 /* Number of leading positions k in [start, maxn) with src[sidx+k] == ref[ridx+k],
- * plus start; 512 pixels per iteration.  Wavefront 0 only. */
+ * plus start.  One wavefront; every load of an iteration is in flight before
+ * the first compare.  Lanes past maxn re-read the last valid group (the arena
+ * is padded, so a group may run a few pixels over its segment). */
 template <int MODE>
-__device__ int glz_match_len(const uint8_t *sbase, int sidx, const uint8_t *rbase, int ridx,
-                             int start, int maxn, int lane)
+__device__ __forceinline__ int glz_match_len(const GLZ_GLOBAL uint8_t *sbase, int sidx,
+                                             const GLZ_GLOBAL uint8_t *rbase, int ridx, int start,
+                                             int maxn, int lane)
 {
     typedef GlzTraits<MODE> T;
     int n = start;
-    while (n < maxn) {
-        uint64_t miss[GLZ_UNROLL];
+    if (MODE == GLZ_MODE_RGB32 || MODE == GLZ_MODE_ALPHA) {
+        const uint32_t mask = glz_raw_mask<MODE>();
+        while (n < maxn) {
+            glz_u32x4 a[GLZ_ROWS], b[GLZ_ROWS];
+            int k[GLZ_ROWS];
 #pragma unroll
-        for (int u = 0; u < GLZ_UNROLL; u++) {
-            const int k = n + u * 64 + lane;
-            bool eq = false;
-            if (k < maxn) {
-                eq = ((glz_load_px<MODE>(sbase, sidx + k) ^ glz_load_px<MODE>(rbase, ridx + k)) &
-                      T::MASK) == 0;
+            for (int u = 0; u < GLZ_ROWS; u++) {
+                k[u] = n + u * 256 + lane * 4;
+                const int kk = k[u] < maxn ? k[u] : maxn - 1;
+                a[u] = *(const GLZ_GLOBAL glz_u32x4_u *)(sbase + (size_t)(sidx + kk) * 4);
+                b[u] = *(const GLZ_GLOBAL glz_u32x4_u *)(rbase + (size_t)(ridx + kk) * 4);
             }
-            miss[u] = __ballot(!eq);
-        }
-        bool stop = false;
+            int sub[GLZ_ROWS];
+            uint64_t stop[GLZ_ROWS];
 #pragma unroll
-        for (int u = 0; u < GLZ_UNROLL; u++) {
-            if (!stop) {
-                if (miss[u]) {
-                    n += __ffsll((unsigned long long)miss[u]) - 1;
-                    stop = true;
-                } else {
-                    n += 64;
+            for (int u = 0; u < GLZ_ROWS; u++) {
+                int valid = maxn - k[u];
+                valid = valid < 0 ? 0 : (valid > 4 ? 4 : valid);
+                const int g = glz_agree4(a[u], b[u], mask);
+                sub[u] = g < valid ? g : valid;
+                stop[u] = __ballot(sub[u] < 4);
+            }
+            bool done = false;
+#pragma unroll
+            for (int u = 0; u < GLZ_ROWS; u++) {
+                if (!done) {
+                    if (stop[u]) {
+                        const int f = __ffsll((unsigned long long)stop[u]) - 1;
+                        n += f * 4 + (int)glz_readlane((uint32_t)sub[u], f);
+                        done = true;
+                    } else {
+                        n += 256;
+                    }
                 }
             }
+            if (done) {
+                break;
+            }
         }
-        if (stop) {
-            break;
+    } else {
+        while (n < maxn) {
+            uint32_t a[GLZ_ROWS * 2], b[GLZ_ROWS * 2];
+#pragma unroll
+            for (int u = 0; u < GLZ_ROWS * 2; u++) {
+                const int k = n + u * 64 + lane;
+                const int kk = k < maxn ? k : maxn - 1;
+                a[u] = glz_load_px<MODE>(sbase, sidx + kk);
+                b[u] = glz_load_px<MODE>(rbase, ridx + kk);
+            }
+            uint64_t stop[GLZ_ROWS * 2];
+#pragma unroll
+            for (int u = 0; u < GLZ_ROWS * 2; u++) {
+                const int k = n + u * 64 + lane;
+                stop[u] = __ballot(k >= maxn || ((a[u] ^ b[u]) & T::MASK) != 0);
+            }
+            bool done = false;
+#pragma unroll
+            for (int u = 0; u < GLZ_ROWS * 2; u++) {
+                if (!done) {
+                    if (stop[u]) {
+                        n += __ffsll((unsigned long long)stop[u]) - 1;
+                        done = true;
+                    } else {
+                        n += 64;
+                    }
+                }
+            }
+            if (done) {
+                break;
+            }
         }
     }
     return n < maxn ? n : maxn;
 }
 
-/* Number of leading positions k < maxn with src[sidx+k] == x.  Wavefront 0 only. */
+/* Number of leading positions k < maxn with src[sidx+k] == x (x as glz_load_px
+ * returns it).  One wavefront. */
 template <int MODE>
-__device__ int glz_run_len(const uint8_t *sbase, int sidx, uint32_t x, int maxn, int lane)
+__device__ __forceinline__ int glz_run_len(const GLZ_GLOBAL uint8_t *sbase, int sidx, uint32_t x,
+                                           int maxn, int lane)
 {
     typedef GlzTraits<MODE> T;
     int n = 0;
-    while (n < maxn) {
-        uint64_t miss[GLZ_UNROLL];
+    if (MODE == GLZ_MODE_RGB32 || MODE == GLZ_MODE_ALPHA) {
+        const uint32_t mask = glz_raw_mask<MODE>();
+        const uint32_t xr = MODE == GLZ_MODE_ALPHA ? (x & 0xffu) << 24 : x;
+        glz_u32x4 xs;
+        xs[0] = xs[1] = xs[2] = xs[3] = xr;
+        while (n < maxn) {
+            glz_u32x4 a[GLZ_ROWS];
+            int k[GLZ_ROWS];
 #pragma unroll
-        for (int u = 0; u < GLZ_UNROLL; u++) {
-            const int k = n + u * 64 + lane;
-            bool eq = false;
-            if (k < maxn) {
-                eq = ((glz_load_px<MODE>(sbase, sidx + k) ^ x) & T::MASK) == 0;
+            for (int u = 0; u < GLZ_ROWS; u++) {
+                k[u] = n + u * 256 + lane * 4;
+                const int kk = k[u] < maxn ? k[u] : maxn - 1;
+                a[u] = *(const GLZ_GLOBAL glz_u32x4_u *)(sbase + (size_t)(sidx + kk) * 4);
             }
-            miss[u] = __ballot(!eq);
-        }
-        bool stop = false;
+            int sub[GLZ_ROWS];
+            uint64_t stop[GLZ_ROWS];
 #pragma unroll
-        for (int u = 0; u < GLZ_UNROLL; u++) {
-            if (!stop) {
-                if (miss[u]) {
-                    n += __ffsll((unsigned long long)miss[u]) - 1;
-                    stop = true;
-                } else {
-                    n += 64;
+            for (int u = 0; u < GLZ_ROWS; u++) {
+                int valid = maxn - k[u];
+                valid = valid < 0 ? 0 : (valid > 4 ? 4 : valid);
+                const int g = glz_agree4(a[u], xs, mask);
+                sub[u] = g < valid ? g : valid;
+                stop[u] = __ballot(sub[u] < 4);
+            }
+            bool done = false;
+#pragma unroll
+            for (int u = 0; u < GLZ_ROWS; u++) {
+                if (!done) {
+                    if (stop[u]) {
+                        const int f = __ffsll((unsigned long long)stop[u]) - 1;
+                        n += f * 4 + (int)glz_readlane((uint32_t)sub[u], f);
+                        done = true;
+                    } else {
+                        n += 256;
+                    }
                 }
             }
+            if (done) {
+                break;
+            }
         }
-        if (stop) {
-            break;
+    } else {
+        while (n < maxn) {
+            uint32_t a[GLZ_ROWS * 2];
+#pragma unroll
+            for (int u = 0; u < GLZ_ROWS * 2; u++) {
+                const int k = n + u * 64 + lane;
+                const int kk = k < maxn ? k : maxn - 1;
+                a[u] = glz_load_px<MODE>(sbase, sidx + kk);
+            }
+            uint64_t stop[GLZ_ROWS * 2];
+#pragma unroll
+            for (int u = 0; u < GLZ_ROWS * 2; u++) {
+                const int k = n + u * 64 + lane;
+                stop[u] = __ballot(k >= maxn || ((a[u] ^ x) & T::MASK) != 0);
+            }
+            bool done = false;
+#pragma unroll
+            for (int u = 0; u < GLZ_ROWS * 2; u++) {
+                if (!done) {
+                    if (stop[u]) {
+                        n += __ffsll((unsigned long long)stop[u]) - 1;
+                        done = true;
+                    } else {
+                        n += 64;
+                    }
+                }
+            }
+            if (done) {
+                break;
+            }
         }
     }
     return n < maxn ? n : maxn;
@@ -430,7 +452,7 @@ __device__ int glz_run_len(const uint8_t *sbase, int sidx, uint32_t x, int maxn,
 
 /* hash of the three pixels at idx, loaded afresh */
 template <int MODE>
-__device__ __forceinline__ uint32_t glz_hash_at(const uint8_t *base, int idx)
+__device__ __forceinline__ uint32_t glz_hash_at(const GLZ_GLOBAL uint8_t *base, int idx)
 {
     typedef GlzTraits<MODE> T;
     return glz_hash3<MODE>(glz_load_px<MODE>(base, idx) & T::MASK,
@@ -440,20 +462,145 @@ __device__ __forceinline__ uint32_t glz_hash_at(const uint8_t *base, int idx)
 
 /* LDS shared by the workgroup */
 struct GlzShared {
-    uint32_t tile[GLZ_TILE];
-    GlzPosInfo info[GLZ_WIN];
+    uint32_t tile[GLZ_TILE];           /* raw pixels of positions ip-1 .. */
+    uint32_t hash[GLZ_WIN];            /* 3-pixel hash of every window position */
+    uint32_t bitmap[GLZ_KEYS * 8];     /* row = hash & (KEYS-1): window positions with that key */
+    uint32_t infoA[GLZ_WIN];           /* scan results, GLZ_A_* / GLZ_B_* */
+    uint32_t infoB[GLZ_WIN];
+    uint32_t g_idist[GLZ_WIN];         /* the table entry's candidate */
+    uint32_t g_pdist[GLZ_WIN];
+    uint32_t g_ref[GLZ_WIN];
+    uint32_t g_seg[GLZ_WIN];
+    uint32_t tok[GLZ_WIN];             /* per match start: length | GLZ_SEL_* << 29 */
+    uint32_t tok_pdist[GLZ_WIN];       /* pixel distance of a GLZ_SEL_DEEP match */
     GlzDevSeg seg_cache[GLZ_SEG_CACHE];
+    uint64_t lit[4], ms[4], ins[4];    /* window positions: literal stops, match starts, table stores */
+    uint64_t neq[4];                   /* ... pixel differs from its predecessor */
+    uint64_t slow[4];                  /* ... stops whose outcome wavefront 0 left in tok[] */
+    uint32_t wave_sum[4];
+    uint32_t tail_h[2];                /* hashes stored beyond the window's end by its last match */
     int next_ip;
+    /* output cursor.  Literal runs are written lazily: a count byte goes out
+     * together with the first literal of every 32 (glz_encoder.c:89-108 writes
+     * it ahead and patches or drops it; the bytes are the same) */
+    uint32_t op;                       /* next byte */
+    uint32_t copy;                     /* literals in the open count byte's run, 0 = none open */
+    uint32_t last_copy;                /* where that count byte is */
 };
 
 __shared__ GlzShared glz_sh;
+
+__device__ __forceinline__ const GLZ_GLOBAL uint8_t *glz_arena(const GlzDevJob &job)
+{
+    return (const GLZ_GLOBAL uint8_t *)(uintptr_t)job.arena;
+}
+
+__device__ __forceinline__ GLZ_GLOBAL uint8_t *glz_out(const GlzDevJob &job)
+{
+    return (GLZ_GLOBAL uint8_t *)(uintptr_t)job.out;
+}
+
+/* a table entry is {segment, pixel}: one aligned 8-byte word, segment in the low half */
+__device__ __forceinline__ uint2 glz_htab_load(const GlzDevJob &job, uint32_t h)
+{
+    const uint64_t e = ((const GLZ_GLOBAL uint64_t *)(uintptr_t)job.htab)[h];
+    return make_uint2((uint32_t)e, (uint32_t)(e >> 32));
+}
+
+__device__ __forceinline__ void glz_htab_store(const GlzDevJob &job, uint32_t h, uint32_t seg, uint32_t pix)
+{
+    ((GLZ_GLOBAL uint64_t *)(uintptr_t)job.htab)[h] = (uint64_t)seg | ((uint64_t)pix << 32);
+}
+
+__device__ __forceinline__ GlzDevSeg glz_load_seg(const GlzDevJob &job, uint32_t idx)
+{
+    const GLZ_GLOBAL glz_u32x4 *p = (const GLZ_GLOBAL glz_u32x4 *)(uintptr_t)(job.segs + idx);
+    const glz_u32x4 a = p[0], b = p[1];
+    GlzDevSeg s;
+    s.pixels_so_far = (uint64_t)a[0] | ((uint64_t)a[1] << 32);
+    s.image_id = (uint64_t)a[2] | ((uint64_t)a[3] << 32);
+    s.arena_off16 = b[0];
+    s.nunits = b[1];
+    s.img_first_delta = b[2];
+    s.flags = b[3];
+    return s;
+}
+
+__device__ __forceinline__ void glz_store_seg(const GlzDevJob &job, uint32_t idx, const GlzDevSeg &s)
+{
+    GLZ_GLOBAL glz_u32x4 *p = (GLZ_GLOBAL glz_u32x4 *)(uintptr_t)(job.segs + idx);
+    glz_u32x4 a, b;
+    a[0] = (uint32_t)s.pixels_so_far;
+    a[1] = (uint32_t)(s.pixels_so_far >> 32);
+    a[2] = (uint32_t)s.image_id;
+    a[3] = (uint32_t)(s.image_id >> 32);
+    b[0] = s.arena_off16;
+    b[1] = s.nunits;
+    b[2] = s.img_first_delta;
+    b[3] = s.flags;
+    p[0] = a;
+    p[1] = b;
+}
+
+#ifdef GLZ_PROFILE
+__device__ unsigned long long glz_prof[32];
+#define PROF_T() wall_clock64()
+#define PROF_ADD_OFF(k, v) do { } while (0)
+__shared__ unsigned long long glz_prof_sh[32];
+#define PROF_ADD(k, v) do { if (threadIdx.x == 0) glz_prof_sh[k] += (unsigned long long)(v); } while (0)
+extern "C" void spice_gpu_debug_prof(unsigned long long *out, int reset)
+{
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(glz_prof), sizeof(glz_prof));
+    if (reset) {
+        unsigned long long z[32] = {0};
+        hipMemcpyToSymbol(HIP_SYMBOL(glz_prof), z, sizeof(z));
+    }
+}
+#else
+#define PROF_T() 0ull
+#define PROF_ADD_OFF(k, v) do { } while (0)
+#define PROF_ADD(k, v) do { } while (0)
+#endif
 
 __device__ __forceinline__ GlzDevSeg glz_seg(const GlzDevJob &job, const GlzShared &sh, uint32_t idx)
 {
     if (idx < GLZ_SEG_CACHE) {
         return sh.seg_cache[idx];
     }
-    return job.segs[idx];
+    return glz_load_seg(job, idx);
+}
+
+__device__ __forceinline__ uint32_t glz_pick4(uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, int w)
+{
+    return w == 0 ? r0 : (w == 1 ? r1 : (w == 2 ? r2 : r3));
+}
+
+__device__ __forceinline__ uint64_t glz_pick4(uint64_t r0, uint64_t r1, uint64_t r2, uint64_t r3, int w)
+{
+    return w == 0 ? r0 : (w == 1 ? r1 : (w == 2 ? r2 : r3));
+}
+
+/* first set bit at or above position `from` of a 256-bit mask, GLZ_WIN if none */
+__device__ __forceinline__ int glz_ffs_from(uint64_t m0, uint64_t m1, uint64_t m2, uint64_t m3, int from)
+{
+    if (from >= GLZ_WIN) {
+        return GLZ_WIN;
+    }
+    const int w = from >> 6, s = from & 63;
+    const uint64_t cur = (glz_pick4(m0, m1, m2, m3, w) >> s) << s;
+    if (cur) {
+        return w * 64 + __ffsll((unsigned long long)cur) - 1;
+    }
+    if (w < 1 && m1) {
+        return 64 + __ffsll((unsigned long long)m1) - 1;
+    }
+    if (w < 2 && m2) {
+        return 128 + __ffsll((unsigned long long)m2) - 1;
+    }
+    if (w < 3 && m3) {
+        return 192 + __ffsll((unsigned long long)m3) - 1;
+    }
+    return GLZ_WIN;
 }
 
 /* Matching pixels between window positions i and j < i, read from the LDS tile
@@ -476,269 +623,792 @@ __device__ __forceinline__ int glz_tile_match_len(const uint32_t *tile, int i, i
     return n < lim ? n : lim;
 }
 
-/* One segment, glz_encode_tmpl.c:268-491.  All 256 lanes call this; GlzOut and
- * copy live in wavefront 0. */
+/* what do_match accepts for a candidate inside the window: image distance 0,
+ * pixel distance < 4096, so three reference bytes (glz_encode_tmpl.c:243-261) */
 template <int MODE>
-__device__ __forceinline__ void glz_parse_seg(const GlzDevJob &job, uint32_t seg_idx, int from,
-                                              int copied, GlzOut &o, int tid)
+__device__ __forceinline__ int glz_accept_near(int len)
 {
-    GlzShared &sh = glz_sh;
     typedef GlzTraits<MODE> T;
-    const int lane = tid & 63;
-    const bool w0 = tid < GLZ_WAVE;
-    const GlzDevSeg cs = glz_seg(job, sh, seg_idx);
-    const uint8_t *base = job.arena + (size_t)cs.arena_off16 * 16;
-    const int npix = (int)cs.nunits;
-    const int ip_bound = npix - 2, ip_limit = npix - 6;
-    int ip = from;
-    int copy = copied;
-
-    if (w0 && copy == 0) {
-        glz_put_copy_count(o, GLZ_MAX_COPY - 1, lane);
+    const int need = 3 / T::ENC_DIV + 1;
+    if (len < T::MIN_REF) {
+        return 0;
     }
+    return (len > T::MAX_REF || len >= need) ? len : 0;
+}
 
-    while (ip < ip_limit) {
-        /* ---------------- step 1: stage the window's pixels, one position per lane */
-        for (int t = tid; t < GLZ_TILE; t += GLZ_THREADS) {
-            const int pos = ip - 1 + t;
-            sh.tile[t] = (pos >= 0 && pos < npix) ? glz_load_px<MODE>(base, pos) : 0u;
+/* Literal pixels [first, first + n) of a segment, n <= 64, appended to the
+ * open literal run straight from the window arena (segment heads and tails,
+ * glz_encode_tmpl.c:466-487,511-541).  closing: the run ends after them.
+ * Wavefront 0 only. */
+template <int MODE>
+__device__ __forceinline__ void glz_run_from_arena(const GlzDevJob &job, const GLZ_GLOBAL uint8_t *base,
+                                                   int first, int n, bool closing, int lane)
+{
+    typedef GlzTraits<MODE> T;
+    GlzShared &sh = glz_sh;
+    const uint32_t op = sh.op, c = sh.copy, lc = sh.last_copy;
+    const bool active = lane < n;
+    const uint32_t r = c + (uint32_t)lane;
+    const bool cs = active && (r & 31) == 0;               /* starts a run of 32 */
+    const uint64_t csmask = __ballot(cs);
+    const uint32_t ctrl_before = (uint32_t)__popcll(csmask & ((1ull << lane) - 1));
+    const uint32_t total = c + (uint32_t)n;
+    uint32_t off = op + (uint32_t)lane * T::LITB + ctrl_before;
+
+    if (active) {
+        if (cs) {
+            const uint32_t left = total - r;
+            glz_put(glz_out(job), job.out_cap, off, closing ? (left < 32 ? left : 32) - 1 : GLZ_MAX_COPY - 1);
+            off++;
         }
-        __syncthreads();
-        {
-            const int p = tid, q = ip + p;
-            const bool act = q < ip_limit;
-            const uint32_t cm1 = sh.tile[p] & T::MASK, c0 = sh.tile[p + 1] & T::MASK;
-            const uint32_t c1 = sh.tile[p + 2] & T::MASK, c2 = sh.tile[p + 3] & T::MASK;
-            const bool rle = act && q > 0 && cm1 == c0 && c0 == c1 && c1 == c2;
-            GlzPosInfo pi;
-            pi.h = glz_hash3<MODE>(c0, c1, c2);
-            pi.flags = (act ? GLZ_F_ACT : 0u) | (rle ? GLZ_F_RLE : 0u);
-            pi.g_ref = pi.g_seg = pi.g_image_dist = pi.g_pix_dist = 0;
-            if (act && !rle) {
-                /* hash probe + do_match (glz_encode_tmpl.c:147-241) against the slot's content */
-                const uint2 he = job.htab[pi.h];
-                const GlzDevSeg rs = glz_seg(job, sh, he.x);
-                const bool valid =
-                    he.x == seg_idx ||
-                    ((rs.flags & GLZ_SEG_USED) && (rs.flags & GLZ_SEG_ALIVE) &&
-                     (rs.flags & GLZ_SEG_TYPE_MASK) == (cs.flags & GLZ_SEG_TYPE_MASK) &&
-                     rs.pixels_so_far <= cs.pixels_so_far && job.head_psf <= rs.pixels_so_far);
-                if (valid && (int64_t)he.y <= (int64_t)rs.nunits - T::MIN_REF) {
-                    const uint64_t idist = cs.image_id - rs.image_id;
-                    uint64_t pdist;
-                    if (idist == 0) {
-                        pdist = ((uint64_t)q + cs.pixels_so_far) - ((uint64_t)he.y + rs.pixels_so_far);
+        glz_put_pixel<MODE>(glz_out(job), job.out_cap, off, glz_load_px<MODE>(base, first + lane));
+    }
+    if (lane == 0) {
+        if (c > 0 && closing) {
+            glz_put(glz_out(job), job.out_cap, lc, (total < 32 ? total : 32) - 1);
+        }
+        if (csmask) {
+            const int kk = 63 - __clzll((long long)csmask);
+            sh.last_copy = op + (uint32_t)kk * T::LITB + (uint32_t)__popcll(csmask & ((1ull << kk) - 1));
+        }
+        sh.op = op + (uint32_t)n * T::LITB + (uint32_t)__popcll(csmask);
+        sh.copy = closing ? 0 : (total & 31);
+    }
+}
+
+/* ---- scan: one window position per lane.  Leaves infoA/infoB and the table
+ * candidate in LDS; returns the lane's hash (for the later table store). */
+template <int MODE>
+__device__ __forceinline__ void glz_window_scan(const GlzDevJob &job, const GlzDevSeg &cs,
+                                                uint32_t seg_idx, const GLZ_GLOBAL uint8_t *base, int ip,
+                                                int npix, int tid, uint32_t &my_h, bool &my_hv)
+{
+    typedef GlzTraits<MODE> T;
+    GlzShared &sh = glz_sh;
+    const int ip_bound = npix - 2, ip_limit = npix - 6;
+    const int p = tid, q = ip + p;
+    const bool act = q < ip_limit;
+    const bool hv = q + 2 < npix;
+    const uint32_t cm1 = sh.tile[p] & T::MASK, c0 = sh.tile[p + 1] & T::MASK;
+    const uint32_t c1 = sh.tile[p + 2] & T::MASK, c2 = sh.tile[p + 3] & T::MASK;
+    const uint32_t h = glz_hash3<MODE>(c0, c1, c2);
+    const bool rle = act && q > 0 && cm1 == c0 && c0 == c1 && c1 == c2;
+    const bool look = act && !rle;
+    uint32_t *row = &sh.bitmap[(h & (GLZ_KEYS - 1)) * 8];
+
+    sh.hash[p] = h;
+    if (hv) {
+        atomicOr(&row[p >> 5], 1u << (p & 31));
+    }
+    /* the table probe travels while the window candidates are worked out */
+    uint2 he = make_uint2(0, 0);
+    if (look) {
+        he = glz_htab_load(job, h);
+    }
+    my_h = h;
+    my_hv = hv;
+    __syncthreads();
+
+    uint32_t A = (act ? GLZ_A_ACT : 0u) | (rle ? GLZ_A_RLE : 0u);
+    uint32_t B = 0;
+    if (look) {
+        const int maxn = ip_bound - q;
+        uint32_t mine[GLZ_K];
+#pragma unroll
+        for (int k = 0; k < GLZ_K; k++) {
+            mine[k] = sh.tile[p + 1 + k] & T::MASK;
+        }
+
+        /* the two nearest earlier positions with this hash */
+        int n1 = -1, n2 = -1;
+        bool more = false; /* a third one exists */
+        for (int v = p >> 5; v >= 0 && !more; v--) {
+            uint32_t bits = row[v];
+            if (v == (p >> 5)) {
+                bits &= (1u << (p & 31)) - 1;
+            }
+            while (bits && !more) {
+                const int b = 31 - __clz((int)bits);
+                bits &= ~(1u << b);
+                const int j = v * 32 + b;
+                if (sh.hash[j] == h) {
+                    if (n1 < 0) {
+                        n1 = j;
+                    } else if (n2 < 0) {
+                        n2 = j;
                     } else {
-                        pdist = (uint64_t)he.y + rs.img_first_delta;
-                    }
-                    if (pdist != 0 && pdist < 33554432ull && idist <= 16777215ull) {
-                        const uint8_t *rbase = job.arena + (size_t)rs.arena_off16 * 16;
-                        const int ref = (int)he.y;
-                        int maxk = ip_bound - q;
-                        const int rmax = (int)rs.nunits - ref;
-                        maxk = rmax < maxk ? rmax : maxk;
-                        const bool capped = maxk > GLZ_K;
-                        maxk = capped ? GLZ_K : maxk;
-                        uint32_t r[GLZ_K];
-#pragma unroll
-                        for (int k = 0; k < GLZ_K; k++) {
-                            r[k] = glz_load_px<MODE>(rbase, ref + (k < maxk ? k : 0));
-                        }
-                        int glen = 0;
-                        bool run = true;
-#pragma unroll
-                        for (int k = 0; k < GLZ_K; k++) {
-                            run = run && k < maxk && ((r[k] ^ sh.tile[p + 1 + k]) & T::MASK) == 0;
-                            glen += run ? 1 : 0;
-                        }
-                        if (glen >= T::MIN_REF) {
-                            pi.flags |= GLZ_F_GOK | ((uint32_t)glen << 8);
-                            if (capped && glen == GLZ_K) {
-                                pi.flags |= GLZ_F_MAXED;
-                            }
-                            pi.g_ref = he.y;
-                            pi.g_seg = he.x;
-                            pi.g_image_dist = (uint32_t)idist;
-                            pi.g_pix_dist = (uint32_t)pdist;
-                        }
+                        more = true;
                     }
                 }
             }
-            sh.info[p] = pi;
         }
-        __syncthreads();
+        A |= more ? GLZ_A_MORE : 0u;
+        if (n1 >= 0) {
+            int len = 0;
+            bool run = true;
+#pragma unroll
+            for (int k = 0; k < GLZ_K; k++) {
+                run = run && k < maxn && (sh.tile[n1 + 1 + k] & T::MASK) == mine[k];
+                len += run ? 1 : 0;
+            }
+            const bool maxed = len == GLZ_K && GLZ_K < maxn;
+            A |= GLZ_A_P1V | ((n1 >> 6) == (p >> 6) ? GLZ_A_P1SAME : 0u) | ((uint32_t)n1 << GLZ_A_P1_SHIFT) |
+                 ((uint32_t)glz_accept_near<MODE>(len) << GLZ_A_LEN1_SHIFT) | (maxed ? GLZ_A_MAX1 : 0u);
+        }
+        if (n2 >= 0) {
+            int len = 0;
+            bool run = true;
+#pragma unroll
+            for (int k = 0; k < GLZ_K; k++) {
+                run = run && k < maxn && (sh.tile[n2 + 1 + k] & T::MASK) == mine[k];
+                len += run ? 1 : 0;
+            }
+            const bool maxed = len == GLZ_K && GLZ_K < maxn;
+            A |= GLZ_A_P2V | ((n2 >> 6) == (p >> 6) ? GLZ_A_P2SAME : 0u);
+            B = (uint32_t)n2 | ((uint32_t)glz_accept_near<MODE>(len) << GLZ_B_LEN2_SHIFT) |
+                (maxed ? GLZ_B_MAX2 : 0u);
+        }
 
-        /* ---------------- step 2: wavefront 0 visits the stops in order */
-        if (w0) {
-            const uint32_t h0r = sh.info[lane].h, h1r = sh.info[64 + lane].h;
-            const uint32_t h2r = sh.info[128 + lane].h, h3r = sh.info[192 + lane].h;
-            const uint32_t f0 = sh.info[lane].flags, f1 = sh.info[64 + lane].flags;
-            const uint32_t f2 = sh.info[128 + lane].flags, f3 = sh.info[192 + lane].flags;
-            GlzMask act_m, rle_m, gok_m;
-            act_m.w0 = __ballot(f0 & GLZ_F_ACT); act_m.w1 = __ballot(f1 & GLZ_F_ACT);
-            act_m.w2 = __ballot(f2 & GLZ_F_ACT); act_m.w3 = __ballot(f3 & GLZ_F_ACT);
-            rle_m.w0 = __ballot(f0 & GLZ_F_RLE); rle_m.w1 = __ballot(f1 & GLZ_F_RLE);
-            rle_m.w2 = __ballot(f2 & GLZ_F_RLE); rle_m.w3 = __ballot(f3 & GLZ_F_RLE);
-            gok_m.w0 = __ballot(f0 & GLZ_F_GOK); gok_m.w1 = __ballot(f1 & GLZ_F_GOK);
-            gok_m.w2 = __ballot(f2 & GLZ_F_GOK); gok_m.w3 = __ballot(f3 & GLZ_F_GOK);
-            GlzMask inserted, lit; /* slots stored in this step; positions pending as literals */
-            glz_mask_clear(inserted);
-            glz_mask_clear(lit);
-            int i = 0;
-            while (i < GLZ_WIN && glz_mask_test(act_m, i)) {
-                const int anchor = ip + i;
+        /* the table's entry: validation + do_match (glz_encode_tmpl.c:147-262) */
+        const GlzDevSeg rs = glz_seg(job, sh, he.x);
+        const bool valid =
+            he.x == seg_idx ||
+            ((rs.flags & GLZ_SEG_USED) && (rs.flags & GLZ_SEG_ALIVE) &&
+             (rs.flags & GLZ_SEG_TYPE_MASK) == (cs.flags & GLZ_SEG_TYPE_MASK) &&
+             rs.pixels_so_far <= cs.pixels_so_far && job.head_psf <= rs.pixels_so_far);
+        if (valid && (int64_t)he.y <= (int64_t)rs.nunits - T::MIN_REF) {
+            const uint64_t idist = cs.image_id - rs.image_id;
+            uint64_t pdist;
+            if (idist == 0) {
+                pdist = ((uint64_t)q + cs.pixels_so_far) - ((uint64_t)he.y + rs.pixels_so_far);
+            } else {
+                pdist = (uint64_t)he.y + rs.img_first_delta;
+            }
+            if (pdist != 0 && pdist < 33554432ull && idist <= 16777215ull) {
+                const GLZ_GLOBAL uint8_t *rbase = glz_arena(job) + (size_t)rs.arena_off16 * 16;
+                const int ref = (int)he.y;
+                int maxk = maxn;
+                const int rmax = (int)rs.nunits - ref;
+                maxk = rmax < maxk ? rmax : maxk;
+                const bool capped = maxk > GLZ_K;
+                maxk = capped ? GLZ_K : maxk;
+                uint32_t r[GLZ_K];
+#pragma unroll
+                for (int k = 0; k < GLZ_K; k++) {
+                    r[k] = glz_load_px<MODE>(rbase, ref + (k < maxk ? k : 0)) & T::MASK;
+                }
                 int len = 0;
-                uint32_t image_dist = 0, pix_dist = 0;
+                bool run = true;
+#pragma unroll
+                for (int k = 0; k < GLZ_K; k++) {
+                    run = run && k < maxk && r[k] == mine[k];
+                    len += run ? 1 : 0;
+                }
+                if (len >= T::MIN_REF && len <= T::MAX_REF) {
+                    /* glz_encode_tmpl.c:243-261 */
+                    const int need = glz_ref_bytes((uint32_t)idist, (uint32_t)pdist) / T::ENC_DIV + 1;
+                    if (len < need) {
+                        len = 0;
+                    }
+                }
+                if (len >= T::MIN_REF) {
+                    A |= ((uint32_t)len << GLZ_A_GLEN_SHIFT) | (capped && len == GLZ_K ? GLZ_A_GMAX : 0u);
+                    sh.g_ref[p] = he.y;
+                    sh.g_seg[p] = he.x;
+                    sh.g_idist[p] = (uint32_t)idist;
+                    sh.g_pdist[p] = (uint32_t)pdist;
+                }
+            }
+        }
+    }
+    sh.infoA[p] = A;
+    sh.infoB[p] = B;
+    {
+        const uint64_t neq = __ballot(c0 != cm1);
+        if ((tid & 63) == 0) {
+            sh.neq[tid >> 6] = neq;
+            sh.lit[tid >> 6] = 0;
+            sh.ms[tid >> 6] = 0;
+            sh.ins[tid >> 6] = 0;
+            sh.slow[tid >> 6] = 0;
+        }
+    }
+}
 
-                if (glz_mask_test(rle_m, i)) {
-                    /* glz_encode_tmpl.c:310-335 */
-                    const uint32_t x = sh.tile[i + 3];
-                    const int maxn = ip_bound - (anchor + 3);
-                    int lim = GLZ_TILE - (i + 4);
-                    lim = lim < maxn ? lim : maxn;
-                    lim = lim < 64 ? lim : 64;
-                    bool eq = false;
-                    if (lane < lim) {
-                        eq = ((sh.tile[i + 4 + lane] ^ x) & T::MASK) == 0;
-                    }
-                    const uint64_t miss = __ballot(!eq);
-                    int n = miss ? __ffsll((unsigned long long)miss) - 1 : 64;
-                    n = n < lim ? n : lim;
-                    if (n == lim && lim < maxn) {
-                        n += glz_run_len<MODE>(base, anchor + 3 + n, x, maxn - n, lane);
-                    }
-                    len = 3 + n;
-                    pix_dist = 1;
-                    image_dist = 0;
+/* stores of one match's tail (window positions t0, t1; -1 = none) that fall into quarter q */
+__device__ __forceinline__ uint64_t glz_tail_bits(int t0, int t1, int q)
+{
+    uint64_t m = 0;
+    if (t0 >= 0 && (t0 >> 6) == q) {
+        m |= 1ull << (t0 & 63);
+    }
+    if (t1 >= 0 && (t1 >> 6) == q) {
+        m |= 1ull << (t1 & 63);
+    }
+    return m;
+}
+
+/* What wavefront 0 keeps per position of the quarter it is walking (one lane
+ * each): the candidates whose fate is not known yet -- earlier positions of the
+ * same quarter -- and what the stop falls back to when neither was stored.
+ * Candidates in finished quarters are settled when the quarter is entered. */
+#define GLZ_W_D2_SHIFT 6      /* 6 bits each: quarter-local index of the candidate, own index = none */
+#define GLZ_W_L1_SHIFT 12     /* 5 bits each: accepted length, or a GLZ_W_LEN_* code */
+#define GLZ_W_L2_SHIFT 17
+#define GLZ_W_LF_SHIFT 22
+#define GLZ_W_SLOW 0x80000000u /* not an ordinary stop: no stop here, or the run test succeeds */
+#define GLZ_W_LEN_MAXED 30     /* the compare has to go on past GLZ_K */
+#define GLZ_W_LEN_DEEP 31      /* an older store to the slot may exist */
+
+template <int MODE>
+__device__ __forceinline__ uint32_t glz_quarter_words(int Q, int lane)
+{
+    GlzShared &sh = glz_sh;
+    const uint32_t *ins32 = (const uint32_t *)sh.ins;
+    const int p = Q * 64 + lane;
+    const uint32_t a = sh.infoA[p], b = sh.infoB[p];
+    if (!(a & GLZ_A_ACT) || (a & GLZ_A_RLE)) {
+        return GLZ_W_SLOW;
+    }
+    uint32_t d1 = (uint32_t)lane, d2 = (uint32_t)lane, l1 = 0, l2 = 0;
+    uint32_t lf = (a & GLZ_A_GMAX) ? GLZ_W_LEN_MAXED : (a >> GLZ_A_GLEN_SHIFT) & 31u;
+    if (a & GLZ_A_P1V) {
+        const uint32_t n1 = (a >> GLZ_A_P1_SHIFT) & 255u, n2 = b & 255u;
+        const uint32_t len1 = (a & GLZ_A_MAX1) ? GLZ_W_LEN_MAXED : (a >> GLZ_A_LEN1_SHIFT) & 31u;
+        const uint32_t len2 = (b & GLZ_B_MAX2) ? GLZ_W_LEN_MAXED : (b >> GLZ_B_LEN2_SHIFT) & 31u;
+        const bool p2v = a & GLZ_A_P2V, more = a & GLZ_A_MORE;
+        if (a & GLZ_A_P1SAME) {
+            d1 = n1 & 63u;
+            l1 = len1;
+            if (p2v) {
+                if (a & GLZ_A_P2SAME) {
+                    d2 = n2 & 63u;
+                    l2 = len2;
+                    lf = more ? GLZ_W_LEN_DEEP : lf;
+                } else if ((ins32[n2 >> 5] >> (n2 & 31u)) & 1u) {
+                    lf = len2;
+                } else if (more) {
+                    lf = GLZ_W_LEN_DEEP;
+                }
+            }
+        } else if ((ins32[n1 >> 5] >> (n1 & 31u)) & 1u) {
+            lf = len1;
+        } else if (p2v) {
+            if ((ins32[n2 >> 5] >> (n2 & 31u)) & 1u) {
+                lf = len2;
+            } else if (more) {
+                lf = GLZ_W_LEN_DEEP;
+            }
+        }
+    }
+    return d1 | (d2 << GLZ_W_D2_SHIFT) | (l1 << GLZ_W_L1_SHIFT) | (l2 << GLZ_W_L2_SHIFT) | (lf << GLZ_W_LF_SHIFT);
+}
+
+/* The stops that need more than the quarter word: runs, compares that go on
+ * past GLZ_K, slots whose two nearest predecessors were both skipped.  Returns
+ * the length; *o_run = the run test succeeded (the stop stores nothing).
+ * ins = stores of the current quarter so far, vfl = those of finished quarters
+ * (lane l, bit q = position 64 q + l). */
+template <int MODE>
+__device__ __forceinline__ int glz_resolve_general(const GlzDevJob &job, const GLZ_GLOBAL uint8_t *base,
+                                                   int ip, int ip_bound, int i, uint64_t ins,
+                                                   uint32_t vfl, uint64_t q0, uint64_t q1, uint64_t q2,
+                                                   uint64_t q3, int lane, bool *o_run)
+{
+    GlzShared &sh = glz_sh;
+    const uint32_t a = glz_uniform(sh.infoA[i]);
+    const int l = i & 63, Q = i >> 6;
+    const int anchor = ip + i;
+    int len = 0;
+    uint32_t sel = GLZ_SEL_RUN;
+
+    *o_run = a & GLZ_A_RLE;
+    if (a & GLZ_A_RLE) {
+        /* glz_encode_tmpl.c:310-335: the run ends at the first pixel that
+         * differs from its predecessor */
+        const int j = glz_ffs_from(q0, q1, q2, q3, i + 3);
+        int end;
+        if (j < GLZ_WIN) {
+            end = ip + j;
+            end = end < ip_bound ? end : ip_bound;
+        } else {
+            int start = ip + GLZ_WIN;
+            start = start > anchor + 3 ? start : anchor + 3;
+            end = ip_bound;
+            if (start < ip_bound) {
+                end = start + glz_run_len<MODE>(base, start, glz_uniform(sh.tile[i + 1]),
+                                                ip_bound - start, lane);
+            }
+        }
+        len = end - anchor;
+    } else {
+        bool maxed = false, table = !(a & GLZ_A_P1V);
+        int cand = 0;
+        if (!table) {
+            const int c1 = (int)((a >> GLZ_A_P1_SHIFT) & 255u);
+            const bool st1 = (a & GLZ_A_P1SAME) ? (ins >> (c1 & 63)) & 1
+                                                : (glz_readlane(vfl, c1 & 63) >> (c1 >> 6)) & 1;
+            if (st1) {
+                len = (int)((a >> GLZ_A_LEN1_SHIFT) & 31u);
+                maxed = a & GLZ_A_MAX1;
+                sel = GLZ_SEL_P1;
+                cand = c1;
+            } else if (!(a & GLZ_A_P2V)) {
+                table = true;
+            } else {
+                const uint32_t b = glz_uniform(sh.infoB[i]);
+                const int c2 = (int)(b & 255u);
+                const bool st2 = (a & GLZ_A_P2SAME) ? (ins >> (c2 & 63)) & 1
+                                                    : (glz_readlane(vfl, c2 & 63) >> (c2 >> 6)) & 1;
+                if (st2) {
+                    len = (int)((b >> GLZ_B_LEN2_SHIFT) & 31u);
+                    maxed = b & GLZ_B_MAX2;
+                    sel = GLZ_SEL_P2;
+                    cand = c2;
+                } else if (!(a & GLZ_A_MORE)) {
+                    table = true;
                 } else {
-                    const uint32_t hi = sh.info[i].h;
-                    /* most recent store to this slot made inside the window, if any */
+                    /* both were skipped: look for an older store to the slot */
+                    const uint32_t hi = glz_uniform(sh.hash[i]);
+                    const uint64_t lo = (1ull << l) - 1;
                     int j = -1;
-                    {
-                        const GlzMask below = glz_mask_below(inserted, i);
-                        const uint64_t m0 = __ballot(h0r == hi) & below.w0;
-                        const uint64_t m1 = __ballot(h1r == hi) & below.w1;
-                        const uint64_t m2 = __ballot(h2r == hi) & below.w2;
-                        const uint64_t m3 = __ballot(h3r == hi) & below.w3;
-                        if (m3) {
-                            j = 192 + 63 - __clzll((long long)m3);
-                        } else if (m2) {
-                            j = 128 + 63 - __clzll((long long)m2);
-                        } else if (m1) {
-                            j = 64 + 63 - __clzll((long long)m1);
-                        } else if (m0) {
-                            j = 63 - __clzll((long long)m0);
+#pragma unroll
+                    for (int w = 0; w < 4; w++) {
+                        if (w <= Q) {
+                            const uint64_t same = __ballot(sh.hash[w * 64 + lane] == hi);
+                            const uint64_t stored = w < Q ? __ballot((vfl >> w) & 1u) : (ins & lo);
+                            const uint64_t m = same & stored;
+                            if (m) {
+                                j = w * 64 + 63 - __clzll((long long)m);
+                            }
                         }
                     }
-                    if (j >= 0) {
-                        const int maxn = ip_bound - anchor; /* ref < anchor: its own limit is laxer */
+                    if (j < 0) {
+                        table = true;
+                    } else {
+                        const int maxn = ip_bound - anchor;
                         int checked = 0;
                         len = glz_tile_match_len<MODE>(sh.tile, i, j, maxn, lane, &checked);
                         if (len == checked && checked < maxn) {
                             len = glz_match_len<MODE>(base, anchor, base, ip + j, len, maxn, lane);
                         }
-                        if (len < T::MIN_REF) {
-                            len = 0;
+                        len = glz_accept_near<MODE>(len);
+                        sel = GLZ_SEL_DEEP;
+                        if (lane == 0) {
+                            sh.tok_pdist[i] = (uint32_t)(i - j);
                         }
-                        image_dist = 0;
-                        pix_dist = (uint32_t)(i - j);
-                    } else if (glz_mask_test(gok_m, i)) {
-                        const GlzPosInfo pi = sh.info[i];
-                        len = (int)(pi.flags >> 8);
-                        image_dist = pi.g_image_dist;
-                        pix_dist = pi.g_pix_dist;
-                        if (pi.flags & GLZ_F_MAXED) {
-                            const GlzDevSeg rs = glz_seg(job, sh, pi.g_seg);
-                            const uint8_t *rbase = job.arena + (size_t)rs.arena_off16 * 16;
-                            int maxn = ip_bound - anchor;
-                            const int rmax = (int)rs.nunits - (int)pi.g_ref;
-                            maxn = rmax < maxn ? rmax : maxn;
-                            len = glz_match_len<MODE>(base, anchor, rbase, (int)pi.g_ref, len, maxn, lane);
-                        }
-                    }
-                    if (len > 0 && len <= T::MAX_REF) {
-                        /* glz_encode_tmpl.c:243-261 */
-                        const int need = glz_ref_bytes(image_dist, pix_dist) / T::ENC_DIV + 1;
-                        if (len < need) {
-                            len = 0;
-                        }
-                    }
-                    /* glz_encode_tmpl.c:381 */
-                    if (lane == 0) {
-                        job.htab[hi] = make_uint2(seg_idx, (uint32_t)anchor);
-                    }
-                    glz_mask_set(inserted, i);
-                }
-
-                if (len == 0) {
-                    glz_mask_set(lit, i);
-                    i++;
-                    continue;
-                }
-
-                /* ---- match, glz_encode_tmpl.c:387-447 */
-                glz_flush_literals<MODE>(o, copy, lit, sh.tile, lane);
-                glz_mask_clear(lit);
-                if (image_dist == 0) {
-                    pix_dist--;
-                }
-                glz_close_copy(o, copy, lane);
-                copy = 0;
-                glz_put_match(o, image_dist, pix_dist, (uint32_t)(len - T::LEN_BIAS), lane);
-                {
-                    const int p0 = anchor + len - 2, p1 = p0 + 1;
-                    const bool ins0 = !T::GUARD_A || p0 > anchor;
-                    const bool ins1 = !T::GUARD_B || p1 > anchor;
-                    const int w0i = p0 - ip, w1i = p1 - ip;
-                    uint32_t h0, h1;
-                    if (w1i < GLZ_WIN) {
-                        /* step 1 hashed every window position whose three pixels exist */
-                        h0 = sh.info[w0i].h;
-                        h1 = sh.info[w1i].h;
-                    } else {
-                        h0 = glz_hash_at<MODE>(base, p0);
-                        h1 = glz_hash_at<MODE>(base, p1);
-                    }
-                    if (lane == 0) {
-                        if (ins0) {
-                            job.htab[h0] = make_uint2(seg_idx, (uint32_t)p0);
-                        }
-                        if (ins1) {
-                            job.htab[h1] = make_uint2(seg_idx, (uint32_t)p1);
-                        }
-                    }
-                    if (w0i < GLZ_WIN && ins0) {
-                        glz_mask_set(inserted, w0i);
-                    }
-                    if (w1i < GLZ_WIN && ins1) {
-                        glz_mask_set(inserted, w1i);
                     }
                 }
-                glz_put_copy_count(o, GLZ_MAX_COPY - 1, lane);
-                i += len;
-            }
-            glz_flush_literals<MODE>(o, copy, lit, sh.tile, lane);
-            if (lane == 0) {
-                sh.next_ip = ip + i; /* i counts every pixel consumed, also past the window */
             }
         }
-        __syncthreads();
-        ip = sh.next_ip;
-        __syncthreads();
+        if (table) {
+            len = (int)((a >> GLZ_A_GLEN_SHIFT) & 31u);
+            maxed = a & GLZ_A_GMAX;
+            sel = GLZ_SEL_TABLE;
+            if (maxed) {
+                const GlzDevSeg rs = glz_seg(job, sh, glz_uniform(sh.g_seg[i]));
+                const GLZ_GLOBAL uint8_t *rbase = glz_arena(job) + (size_t)rs.arena_off16 * 16;
+                const int ref = (int)glz_uniform(sh.g_ref[i]);
+                int maxn = ip_bound - anchor;
+                const int rmax = (int)rs.nunits - ref;
+                maxn = rmax < maxn ? rmax : maxn;
+                len = glz_match_len<MODE>(base, anchor, rbase, ref, len, maxn, lane);
+            }
+        } else if (maxed) {
+            len = glz_match_len<MODE>(base, anchor, base, ip + cand, len, ip_bound - anchor, lane);
+        }
+    }
+    len = (int)glz_uniform((uint32_t)len); /* every lane holds the same value already */
+    sel = glz_uniform(sel);
+    if (lane == 0) {
+        sh.tok[i] = (uint32_t)len | (sel << 29);
+    }
+    return len;
+}
+
+/* ---- resolve: wavefront 0 walks the stops of the window in order, a quarter
+ * (64 positions) at a time so that the quarter's marks are 64-bit scalars.
+ * Publishes per quarter: stops that became matches (ms) or literals (lit),
+ * table stores (ins), and the stops whose outcome is in tok[] (slow). */
+template <int MODE>
+__device__ __forceinline__ void glz_window_resolve(const GlzDevJob &job, uint32_t seg_idx,
+                                                   const GLZ_GLOBAL uint8_t *base, int ip, int npix,
+                                                   int lane)
+{
+    typedef GlzTraits<MODE> T;
+    GlzShared &sh = glz_sh;
+    const int ip_bound = npix - 2;
+    const uint64_t q0 = glz_uniform64(sh.neq[0]), q1 = glz_uniform64(sh.neq[1]);
+    const uint64_t q2 = glz_uniform64(sh.neq[2]), q3 = glz_uniform64(sh.neq[3]);
+    uint32_t vfl = 0;
+    int i = 0;
+    int t0 = -1, t1 = -1; /* stores of the last match's tail that lie beyond its quarter */
+    int qnext = 0;        /* first quarter whose marks are not published yet */
+    bool open = true;
+
+    while (open && i < GLZ_WIN) {
+        const int Q = i >> 6;
+        unsigned long long tqa = PROF_T();
+        /* quarters a match jumped over hold nothing but its tail's stores */
+        for (int q = qnext; q < Q; q++) {
+            const uint64_t m = glz_tail_bits(t0, t1, q);
+            if (lane == 0) {
+                sh.ins[q] = m;
+            }
+            vfl |= (uint32_t)((m >> lane) & 1) << q;
+        }
+        uint64_t ins = glz_tail_bits(t0, t1, Q), stops = 0, ms = 0, slow = 0;
+        __builtin_amdgcn_wave_barrier(); /* lane 0's marks of the finished quarters are read below */
+        const uint32_t W = glz_quarter_words<MODE>(Q, lane);
+        int l = i & 63;
+        int last_len = 0;
+        unsigned long long tqb = PROF_T();
+        PROF_ADD(6, tqb - tqa); PROF_ADD(7, 1);
+
+        while (l < 64) {
+            const uint32_t w = glz_readlane(W, l);
+            const uint64_t bit = 1ull << l;
+            int len;
+            bool general = w & GLZ_W_SLOW;
+            if (!general) {
+                const int d1 = (int)(w & 63u), d2 = (int)((w >> GLZ_W_D2_SHIFT) & 63u);
+                len = ((ins >> d2) & 1) ? (int)((w >> GLZ_W_L2_SHIFT) & 31u) : (int)((w >> GLZ_W_LF_SHIFT) & 31u);
+                len = ((ins >> d1) & 1) ? (int)((w >> GLZ_W_L1_SHIFT) & 31u) : len;
+                general = len >= GLZ_W_LEN_MAXED;
+            }
+            bool own = true;
+            if (general) {
+                if (!(glz_uniform(sh.infoA[Q * 64 + l]) & GLZ_A_ACT)) {
+                    open = false; /* the segment's last stops are behind us */
+                    break;
+                }
+                bool run;
+                unsigned long long tg_ = PROF_T();
+                len = glz_resolve_general<MODE>(job, base, ip, ip_bound, Q * 64 + l, ins, vfl, q0, q1, q2, q3,
+                                                lane, &run);
+                PROF_ADD(8, 1); PROF_ADD(9, PROF_T() - tg_);
+                own = !run;
+                slow |= bit;
+            }
+            /* the stop stored its position unless it was a run (glz_encode_tmpl.c:381) */
+            ins |= own ? bit : 0;
+            stops |= bit;
+            ms |= len ? bit : 0;
+            /* the two positions stored after a match, glz_encode_tmpl.c:424-444 */
+            {
+                const uint64_t tm = len ? ((!T::GUARD_A || len > 2 ? 1ull : 0ull) | (!T::GUARD_B || len > 1 ? 2ull : 0ull)) : 0ull;
+                const int sh0 = l + len - 2;
+                ins |= sh0 < 64 ? (sh0 >= 0 ? tm << sh0 : tm >> 1) : 0ull;
+            }
+            last_len = len;
+            l += len ? len : 1;
+        }
+
+        unsigned long long tqc = PROF_T();
+        PROF_ADD(10, tqc - tqb);
+        i = Q * 64 + l;
+        t0 = t1 = -1;
+        if (open && last_len) {
+            /* the part of the last match's tail that lies beyond this quarter */
+            const int p0 = i - 2, p1 = i - 1;
+            if ((!T::GUARD_A || last_len > 2) && p0 >= (Q + 1) * 64) {
+                t0 = p0;
+            }
+            if ((!T::GUARD_B || last_len > 1) && p1 >= (Q + 1) * 64) {
+                t1 = p1;
+            }
+        }
+        if (lane == 0) {
+            sh.ins[Q] = ins;
+            sh.lit[Q] = stops & ~ms;
+            sh.ms[Q] = ms;
+            sh.slow[Q] = slow;
+        }
+        vfl |= (uint32_t)((ins >> lane) & 1) << Q;
+        qnext = Q + 1;
+        PROF_ADD(11, PROF_T() - tqc);
+    }
+    /* quarters behind the last one walked: only tail stores can be in them */
+    for (int q = qnext; q < 4; q++) {
+        const uint64_t m = glz_tail_bits(t0, t1, q);
+        if (lane == 0) {
+            sh.ins[q] = m;
+        }
     }
 
-    /* ---- leftovers as literals, glz_encode_tmpl.c:466-487 */
+    /* stores beyond the window: in the order the reference makes them,
+     * glz_encode_tmpl.c:424-444 */
+    uint32_t th0 = GLZ_NO_HASH, th1 = GLZ_NO_HASH;
+    if (t0 >= GLZ_WIN) {
+        th0 = glz_hash_at<MODE>(base, ip + t0);
+    }
+    if (t1 >= GLZ_WIN) {
+        th1 = glz_hash_at<MODE>(base, ip + t1);
+    }
+    if (lane == 0) {
+        sh.next_ip = ip + i; /* i counts every pixel consumed, also past the window */
+        sh.tail_h[0] = th0;
+        sh.tail_h[1] = th1;
+        if (t0 >= GLZ_WIN) {
+            glz_htab_store(job, th0, seg_idx, (uint32_t)(ip + t0));
+        }
+        if (t1 >= GLZ_WIN) {
+            glz_htab_store(job, th1, seg_idx, (uint32_t)(ip + t1));
+        }
+    }
+}
+
+/* ---- emit: every lane writes the token of its own window position, and the
+ * window's table stores go out (the last store to a slot wins) */
+template <int MODE>
+__device__ __forceinline__ void glz_window_emit(const GlzDevJob &job, uint32_t seg_idx, int ip,
+                                                int tid, uint32_t my_h, bool my_hv)
+{
+    typedef GlzTraits<MODE> T;
+    GlzShared &sh = glz_sh;
+    const int lane = tid & 63, p = tid;
+    const int w = (int)glz_uniform((uint32_t)(tid >> 6));
+    const uint64_t lit0 = glz_uniform64(sh.lit[0]), lit1 = glz_uniform64(sh.lit[1]);
+    const uint64_t lit2 = glz_uniform64(sh.lit[2]), lit3 = glz_uniform64(sh.lit[3]);
+    const uint64_t ms0 = glz_uniform64(sh.ms[0]), ms1 = glz_uniform64(sh.ms[1]);
+    const uint64_t ms2 = glz_uniform64(sh.ms[2]), ms3 = glz_uniform64(sh.ms[3]);
+    const uint64_t lit[4] = {lit0, lit1, lit2, lit3};
+    const uint64_t ms[4] = {ms0, ms1, ms2, ms3};
+    const uint32_t op_in = glz_uniform(sh.op), c0 = glz_uniform(sh.copy), lc_in = glz_uniform(sh.last_copy);
+    const uint64_t below = (1ull << lane) - 1;
+
+    /* (1) table stores: a stored position writes its slot unless a later store
+     * of this window (or of its last match's tail) goes to the same slot */
+    {
+        const uint32_t *ins32 = (const uint32_t *)sh.ins;
+        if (my_hv && ((ins32[p >> 5] >> (p & 31)) & 1u)) {
+            bool dominated = my_h == sh.tail_h[0] || my_h == sh.tail_h[1];
+            const uint32_t *row = &sh.bitmap[(my_h & (GLZ_KEYS - 1)) * 8];
+            for (int v = p >> 5; v < 8 && !dominated; v++) {
+                uint32_t bits = row[v] & ins32[v];
+                if (v == (p >> 5)) {
+                    bits &= ~((2u << (p & 31)) - 1);
+                }
+                while (bits && !dominated) {
+                    const int b = __ffs((int)bits) - 1;
+                    bits &= bits - 1;
+                    dominated = sh.hash[v * 32 + b] == my_h;
+                }
+            }
+            if (!dominated) {
+                glz_htab_store(job, my_h, seg_idx, (uint32_t)(ip + p));
+            }
+        }
+    }
+
+    /* (2) where this wavefront's 64 positions stand in the literal runs */
+    uint32_t carry = c0;     /* literals of the open run before this wavefront's positions */
+    bool nomatch = true;     /* ... and no match starts before them in the window */
+    uint32_t after = 0;      /* literals behind them up to the next match start */
+    bool closes = false;     /* ... if there is one */
+    uint32_t run_end = c0;   /* literals of the run that stays open at the window's end */
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+        if (ms[v]) {
+            const int lm = 63 - __clzll((long long)ms[v]);
+            const uint32_t tail = (uint32_t)__popcll((lit[v] >> lm) >> 1);
+            if (v < w) {
+                carry = tail;
+                nomatch = false;
+            }
+            run_end = tail;
+        } else {
+            const uint32_t n = (uint32_t)__popcll(lit[v]);
+            if (v < w) {
+                carry += n;
+            }
+            run_end += n;
+        }
+        if (v > w && !closes) {
+            if (ms[v]) {
+                const int fm = __ffsll((unsigned long long)ms[v]) - 1;
+                after += (uint32_t)__popcll(lit[v] & ((1ull << fm) - 1));
+                closes = true;
+            } else {
+                after += (uint32_t)__popcll(lit[v]);
+            }
+        }
+    }
+    const uint64_t litw = glz_pick4(lit0, lit1, lit2, lit3, w);
+    const uint64_t msw = glz_pick4(ms0, ms1, ms2, ms3, w);
+    const bool is_lit = (litw >> lane) & 1, is_ms = (msw >> lane) & 1;
+
+    /* r: literals of the current run before this position */
+    uint32_t r;
+    bool first_run; /* the run reaches back beyond the window */
+    {
+        const uint64_t msb = msw & below, litb = litw & below;
+        if (msb) {
+            const int lm = 63 - __clzll((long long)msb);
+            r = (uint32_t)__popcll((litb >> lm) >> 1);
+            first_run = false;
+        } else {
+            r = carry + (uint32_t)__popcll(litb);
+            first_run = nomatch;
+        }
+    }
+    /* rem: literals of the run from this position on; closed: a match ends it in this window */
+    uint32_t rem;
+    bool closed;
+    {
+        const uint64_t msa = (msw >> lane) >> 1, lita = litw >> lane;
+        if (msa) {
+            const int d = __ffsll((unsigned long long)msa) - 1;
+            rem = (uint32_t)__popcll(lita & ((2ull << d) - 1));
+            closed = true;
+        } else {
+            rem = (uint32_t)__popcll(lita) + after;
+            closed = closes;
+        }
+    }
+
+    uint32_t bytes = 0, elen = 0, idist = 0, pdist = 0, nff = 0;
+    bool cs = false;
+    if (is_lit) {
+        cs = (r & 31) == 0;
+        bytes = T::LITB + (cs ? 1u : 0u);
+    } else if (is_ms) {
+        const uint32_t *ins32 = (const uint32_t *)sh.ins;
+        const uint32_t a = sh.infoA[p], b = sh.infoB[p];
+        const uint32_t n1 = (a >> GLZ_A_P1_SHIFT) & 255u, n2 = b & 255u;
+        uint32_t tok;
+        if ((sh.slow[p >> 6] >> lane) & 1) {
+            tok = sh.tok[p];
+        } else if ((a & GLZ_A_P1V) && ((ins32[n1 >> 5] >> (n1 & 31u)) & 1u)) {
+            /* the same choice wavefront 0 made, now that every store is known */
+            tok = ((a >> GLZ_A_LEN1_SHIFT) & 31u) | (GLZ_SEL_P1 << 29);
+        } else if ((a & GLZ_A_P2V) && ((ins32[n2 >> 5] >> (n2 & 31u)) & 1u)) {
+            tok = ((b >> GLZ_B_LEN2_SHIFT) & 31u) | (GLZ_SEL_P2 << 29);
+        } else {
+            tok = ((a >> GLZ_A_GLEN_SHIFT) & 31u) | (GLZ_SEL_TABLE << 29);
+        }
+        const uint32_t sel = tok >> 29;
+        if (sel == GLZ_SEL_P1) {
+            pdist = (uint32_t)p - n1;
+        } else if (sel == GLZ_SEL_P2) {
+            pdist = (uint32_t)p - n2;
+        } else if (sel == GLZ_SEL_TABLE) {
+            idist = sh.g_idist[p];
+            pdist = sh.g_pdist[p];
+        } else if (sel == GLZ_SEL_RUN) {
+            pdist = 1;
+        } else {
+            pdist = sh.tok_pdist[p];
+        }
+        if (idist == 0) {
+            pdist--; /* glz_encode_tmpl.c:389-391 */
+        }
+        elen = (tok & GLZ_TOK_LEN_MASK) - T::LEN_BIAS;
+        bytes = glz_match_bytes(idist, pdist, elen);
+        nff = elen >= 7 ? (elen - 7) / 255u : 0;
+    }
+
+    /* (3) byte offsets: prefix sum over the 256 positions */
+    uint32_t incl = bytes;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, (unsigned)d);
+        incl += lane >= d ? up : 0u;
+    }
+    if (lane == 63) {
+        sh.wave_sum[w] = incl;
+    }
+    __syncthreads();
+    const uint32_t ws0 = sh.wave_sum[0], ws1 = sh.wave_sum[1], ws2 = sh.wave_sum[2], ws3 = sh.wave_sum[3];
+    uint32_t off = op_in + incl - bytes + (w > 0 ? ws0 : 0u) + (w > 1 ? ws1 : 0u) + (w > 2 ? ws2 : 0u);
+
+    /* (4) write */
+    if (is_lit) {
+        if (cs) {
+            glz_put(glz_out(job), job.out_cap, off, closed ? (rem < 32 ? rem : 32) - 1 : GLZ_MAX_COPY - 1);
+            if (!closed && rem <= 32) {
+                sh.last_copy = off; /* the count byte a later window may have to patch */
+            }
+            off++;
+        }
+        glz_put_pixel<MODE>(glz_out(job), job.out_cap, off, sh.tile[p + 1]);
+    } else if (is_ms) {
+        if (first_run && c0 > 0 && r < 32) {
+            glz_put(glz_out(job), job.out_cap, lc_in, r - 1); /* glz_encoder.c:95-108 */
+        }
+        glz_write_match(glz_out(job), job.out_cap, off, idist, pdist, elen, 16);
+    }
+    {
+        uint64_t big = __ballot(is_ms && nff > 16);
+        while (big) {
+            const int src = __ffsll((unsigned long long)big) - 1;
+            big &= big - 1;
+            const uint32_t o2 = __shfl(off, src), n2 = __shfl(nff, src);
+            for (uint32_t t = (uint32_t)lane; t < n2; t += GLZ_WAVE) {
+                glz_put(glz_out(job), job.out_cap, o2 + 1 + t, 255u);
+            }
+        }
+    }
+    if (tid == 0) {
+        sh.op = op_in + ws0 + ws1 + ws2 + ws3;
+        sh.copy = run_end & 31;
+    }
+    /* the bitmap is clean again for the next window */
+    if (my_hv) {
+        sh.bitmap[(my_h & (GLZ_KEYS - 1)) * 8 + (p >> 5)] = 0;
+    }
+}
+
+/* One segment, glz_encode_tmpl.c:268-491.  All 256 lanes call this.
+ * from: first position to parse (2 in an image's first segment, whose two
+ * leading pixels are already out as literals). */
+template <int MODE>
+__device__ __forceinline__ void glz_parse_seg(const GlzDevJob &job, uint32_t seg_idx, int from, int tid)
+{
+    GlzShared &sh = glz_sh;
+    const int lane = tid & 63;
+    const bool w0 = tid < GLZ_WAVE;
+    const GlzDevSeg cs = glz_seg(job, sh, seg_idx);
+    const GLZ_GLOBAL uint8_t *base = glz_arena(job) + (size_t)cs.arena_off16 * 16;
+    const int npix = (int)cs.nunits;
+    const int ip_limit = npix - 6;
+    int ip = from;
+
+    while (ip < ip_limit) {
+        unsigned long long ta = PROF_T();
+        for (int t = tid; t < GLZ_TILE; t += GLZ_THREADS) {
+            const int pos = ip - 1 + t;
+            sh.tile[t] = (pos >= 0 && pos < npix) ? glz_load_px<MODE>(base, pos) : 0u;
+        }
+        __syncthreads();
+        unsigned long long tb = PROF_T();
+        uint32_t my_h;
+        bool my_hv;
+        glz_window_scan<MODE>(job, cs, seg_idx, base, ip, npix, tid, my_h, my_hv);
+        __syncthreads();
+        unsigned long long tc = PROF_T();
+        if (w0) {
+            glz_window_resolve<MODE>(job, seg_idx, base, ip, npix, lane);
+        }
+        __syncthreads();
+        unsigned long long td = PROF_T();
+        glz_window_emit<MODE>(job, seg_idx, ip, tid, my_h, my_hv);
+        __syncthreads();
+        unsigned long long te = PROF_T();
+        PROF_ADD(0, tb - ta); PROF_ADD(1, tc - tb); PROF_ADD(2, td - tc); PROF_ADD(3, te - td); PROF_ADD(4, 1);
+        ip = sh.next_ip;
+    }
+
+    /* ---- leftovers as literals, then the run closes; glz_encode_tmpl.c:466-487 */
     if (w0) {
-        glz_literals_from_arena<MODE>(o, copy, base, ip, npix - ip, sh.tile, lane);
-        glz_close_copy(o, copy, lane);
+        glz_run_from_arena<MODE>(job, base, ip, npix - ip, true, lane);
     }
     __syncthreads();
 }
 
 /* glz_encode_tmpl.c:498-555 */
 template <int MODE>
-__device__ __forceinline__ void glz_parse_image(const GlzDevJob &job, const uint32_t *seg_list,
-                                                GlzOut &o, int tid)
+__device__ __forceinline__ void glz_parse_image(const GlzDevJob &job, const uint32_t *seg_list, int tid)
 {
     GlzShared &sh = glz_sh;
     const int lane = tid & 63;
@@ -752,11 +1422,10 @@ __device__ __forceinline__ void glz_parse_image(const GlzDevJob &job, const uint
             break;
         }
         if (cs.nunits > 0 && w0) {
-            const uint8_t *base = job.arena + (size_t)cs.arena_off16 * 16;
-            int copy = 0;
-            glz_put_copy_count(o, cs.nunits - 1, lane);
-            glz_literals_from_arena<MODE>(o, copy, base, 0, (int)cs.nunits, sh.tile, lane);
+            const GLZ_GLOBAL uint8_t *base = glz_arena(job) + (size_t)cs.arena_off16 * 16;
+            glz_run_from_arena<MODE>(job, base, 0, (int)cs.nunits, true, lane);
         }
+        __syncthreads();
     }
     bool first = true;
     for (; s < job.nsegs; s++) {
@@ -765,17 +1434,15 @@ __device__ __forceinline__ void glz_parse_image(const GlzDevJob &job, const uint
             /* the first real segment starts with a hash insert and two literals */
             if (w0) {
                 const GlzDevSeg cs = glz_seg(job, sh, sid);
-                const uint8_t *base = job.arena + (size_t)cs.arena_off16 * 16;
-                int copy = 0;
-                glz_put_copy_count(o, GLZ_MAX_COPY - 1, lane);
+                const GLZ_GLOBAL uint8_t *base = glz_arena(job) + (size_t)cs.arena_off16 * 16;
                 if (lane == 0) {
-                    job.htab[glz_hash_at<MODE>(base, 0)] = make_uint2(sid, 0);
+                    glz_htab_store(job, glz_hash_at<MODE>(base, 0), sid, 0);
                 }
-                glz_literals_from_arena<MODE>(o, copy, base, 0, 2, sh.tile, lane);
+                glz_run_from_arena<MODE>(job, base, 0, 2, false, lane);
             }
             __syncthreads();
         }
-        glz_parse_seg<MODE>(job, sid, first ? 2 : 0, first ? 2 : 0, o, tid);
+        glz_parse_seg<MODE>(job, sid, first ? 2 : 0, tid);
         first = false;
     }
 }
@@ -794,23 +1461,23 @@ glz_parse_kernel(const GlzDevJob *__restrict__ jobs, const uint32_t *__restrict_
     }
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
+#ifdef GLZ_PROFILE
+    if (tid < 32) {
+        glz_prof_sh[tid] = 0;
+    }
+#endif
 
     for (uint32_t u = (uint32_t)tid; u < job.nupd; u += GLZ_THREADS) {
         const GlzDevSegUpdate up = upd_pool[job.upd_off + u];
-        job.segs[up.index] = up.seg;
+        glz_store_seg(job, up.index, up.seg);
+    }
+    for (int t = tid; t < GLZ_KEYS * 8; t += GLZ_THREADS) {
+        sh.bitmap[t] = 0;
     }
     __syncthreads();
     if (tid < GLZ_SEG_CACHE) {
-        sh.seg_cache[tid] = job.segs[tid];
+        sh.seg_cache[tid] = glz_load_seg(job, (uint32_t)tid);
     }
-    __syncthreads();
-
-    GlzOut o;
-    o.buf = job.out;
-    o.cap = job.out_cap;
-    o.op = 0;
-    o.last_copy = 0;
-    o.high = 0;
 
     if (tid < GLZ_HEADER_BYTES) {
         uint32_t b;
@@ -835,24 +1502,36 @@ glz_parse_kernel(const GlzDevJob *__restrict__ jobs, const uint32_t *__restrict_
         } else {
             b = (job.win_head_dist >> (8 * (32 - lane))) & 0xff;
         }
-        glz_put(o, (uint32_t)lane, b);
+        glz_put(glz_out(job), job.out_cap, (uint32_t)lane, b);
     }
-    glz_advance(o, GLZ_HEADER_BYTES);
+    if (tid == 0) {
+        sh.op = GLZ_HEADER_BYTES;
+        sh.copy = 0;
+        sh.last_copy = 0;
+    }
+    __syncthreads();
 
     const uint32_t *seg_list = u32_pool + job.seg_list_off;
     if (TYPE == 6) {
-        glz_parse_image<GLZ_MODE_RGB16>(job, seg_list, o, tid);
+        glz_parse_image<GLZ_MODE_RGB16>(job, seg_list, tid);
     } else if (TYPE == 7) {
-        glz_parse_image<GLZ_MODE_RGB24>(job, seg_list, o, tid);
+        glz_parse_image<GLZ_MODE_RGB24>(job, seg_list, tid);
     } else {
-        glz_parse_image<GLZ_MODE_RGB32>(job, seg_list, o, tid);
+        glz_parse_image<GLZ_MODE_RGB32>(job, seg_list, tid);
         if (TYPE == 9) {
             __syncthreads();
-            glz_parse_image<GLZ_MODE_ALPHA>(job, seg_list, o, tid);
+            glz_parse_image<GLZ_MODE_ALPHA>(job, seg_list, tid);
         }
     }
+    __syncthreads();
+#ifdef GLZ_PROFILE
+    if (tid < 32 && blockIdx.x == 0) {
+        glz_prof[tid] += glz_prof_sh[tid];
+    }
+#endif
     if (tid == 0) {
-        *job.result = o.high > o.cap ? GLZ_DEV_ERR_NO_SPACE : (int32_t)o.op;
+        const uint32_t op = sh.op;
+        *job.result = op > job.out_cap ? GLZ_DEV_ERR_NO_SPACE : (int32_t)op;
     }
 }
 

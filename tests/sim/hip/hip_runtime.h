@@ -176,6 +176,10 @@ static inline T __shfl_xor(T v, int m, int width = 64)
 static inline int __builtin_amdgcn_readfirstlane(int v) { return sim_shfl(v, 1, 0); }
 static inline int __builtin_amdgcn_readlane(int v, int lane) { return sim_shfl(v, 1, lane); }
 static inline int __all(int pred) { return __ballot(!pred) == 0; }
+/* On the GPU the lanes of a wavefront run in lockstep, so this is only a
+ * scheduling fence; here it is what orders one lane's LDS write before the
+ * other lanes' reads. */
+static inline void __builtin_amdgcn_wave_barrier() { (void)sim_exchange64(0, -1, 0, 0); }
 
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline int __popc(unsigned v) { return __builtin_popcount(v); }

@@ -5,6 +5,7 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
 #include <sys/mman.h>
 #include <time.h>
 #include <unistd.h>
@@ -125,8 +126,11 @@ void rendezvous_block()
 
 } // namespace
 
+static void *wait_site[4096]; /* where each fiber last entered a collective */
+
 void sim_barrier(int)
 {
+    wait_site[cur_fiber] = __builtin_return_address(0);
     rendezvous_block();
 }
 
@@ -134,6 +138,7 @@ uint64_t sim_exchange64(uint64_t v, int, int mode, int arg)
 {
     int tid = cur_fiber, wave = tid / 64, lane = tid % 64, width = wave_width(wave);
     uint64_t r = 0;
+    wait_site[tid] = __builtin_return_address(0);
     slot[tid] = v;
     rendezvous_wave(wave);
     const uint64_t *s = &slot[wave * 64];
@@ -210,6 +215,16 @@ void sim_run_grid(dim3 grid, dim3 block, const std::function<void()> &body)
             if (live > 0 && progress == before) {
                 fprintf(stderr, "sim: deadlock -- a collective was not reached by every "
                                 "work-item of block (%u,%u,%u)\n", bx, by, bz);
+                for (int i = 0; i < threads; i++) {
+                    if (!fibers[i].done && (i == 0 || wait_site[i] != wait_site[i - 1])) {
+                        Dl_info di;
+                        memset(&di, 0, sizeof(di));
+                        dladdr(wait_site[i], &di);
+                        fprintf(stderr, "sim:   work-item %d waits at +0x%lx (addr2line -e %s)\n", i,
+                                (unsigned long)((char *)wait_site[i] - (char *)di.dli_fbase),
+                                di.dli_fname ? di.dli_fname : "?");
+                    }
+                }
                 abort();
             }
         }
