@@ -40,7 +40,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="glz1080", choices=["glz1080", "mjpeg2160"])
-    ap.add_argument("--sessions", type=int, default=256, help="GLZ display sessions per GPU")
+    ap.add_argument("--sessions", type=int, default=1024, help="GLZ display sessions per GPU")
     ap.add_argument("--frames", type=int, default=16, help="MJPEG frames per step per GPU")
     ap.add_argument("--pool", type=int, default=8, help="distinct synthetic sequences per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -130,7 +130,7 @@ class GlzWorkload:
         from oracle import oracle as O
         from spice_amd import frames
         threads = max(1, min(16, os.cpu_count() or 1))
-        nfr = 12
+        nfr = 64
         seqs = []
         for t in range(threads):
             seq = frames.DesktopSequence(W1080, H1080, seed=5000 + t)

@@ -15,7 +15,7 @@ encs=[B.GlzEncoder(gpu,d,0) for d in dicts]
 cap=gpu.L.spice_gpu_glz_out_bound(8,W,H)
 outs=[gpu.malloc(cap) for s in range(S)]
 prof=(ctypes.c_ulonglong*32)()
-names=['tile','scan','resolve','emit','windows','x5','qsetup_t','quarters','general','general_t','loop_t','qpub_t','x12','x13','x14','x15']
+names=['tile','scan','resolve','emit','windows','x5','qsetup_t','quarters','general','general_t','loop_t','qpub_t','x12','x13','x14','x15','sc_bar_t','sc_search_t','sc_tabissue_t','sc_all_t','em_stores_t','em_runs_t','em_tok_t','em_scan_t','em_write_t']
 for k in range(NF):
     items=[dict(encoder=encs[s],type=8,width=W,height=H,stride=W*4,chunks=[dev[k]],chunk_rows=[H],out=outs[s],out_capacity=cap) for s in range(S)]
     L.spice_gpu_debug_prof(prof,1)

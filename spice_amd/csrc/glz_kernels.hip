@@ -473,6 +473,7 @@ struct GlzShared {
     uint32_t g_seg[GLZ_WIN];
     uint32_t tok[GLZ_WIN];             /* per match start: length | GLZ_SEL_* << 29 */
     uint32_t tok_pdist[GLZ_WIN];       /* pixel distance of a GLZ_SEL_DEEP match */
+    uint32_t qword[GLZ_WIN];           /* GLZ_W_*: what wavefront 0 walked on */
     GlzDevSeg seg_cache[GLZ_SEG_CACHE];
     uint64_t lit[4], ms[4], ins[4];    /* window positions: literal stops, match starts, table stores */
     uint64_t neq[4];                   /* ... pixel differs from its predecessor */
@@ -542,25 +543,6 @@ __device__ __forceinline__ void glz_store_seg(const GlzDevJob &job, uint32_t idx
     p[1] = b;
 }
 
-#ifdef GLZ_PROFILE
-__device__ unsigned long long glz_prof[32];
-#define PROF_T() wall_clock64()
-#define PROF_ADD_OFF(k, v) do { } while (0)
-__shared__ unsigned long long glz_prof_sh[32];
-#define PROF_ADD(k, v) do { if (threadIdx.x == 0) glz_prof_sh[k] += (unsigned long long)(v); } while (0)
-extern "C" void spice_gpu_debug_prof(unsigned long long *out, int reset)
-{
-    hipMemcpyFromSymbol(out, HIP_SYMBOL(glz_prof), sizeof(glz_prof));
-    if (reset) {
-        unsigned long long z[32] = {0};
-        hipMemcpyToSymbol(HIP_SYMBOL(glz_prof), z, sizeof(z));
-    }
-}
-#else
-#define PROF_T() 0ull
-#define PROF_ADD_OFF(k, v) do { } while (0)
-#define PROF_ADD(k, v) do { } while (0)
-#endif
 
 __device__ __forceinline__ GlzDevSeg glz_seg(const GlzDevJob &job, const GlzShared &sh, uint32_t idx)
 {
@@ -707,69 +689,57 @@ __device__ __forceinline__ void glz_window_scan(const GlzDevJob &job, const GlzD
     }
     my_h = h;
     my_hv = hv;
+    {
+        const uint64_t neq = __ballot(c0 != cm1);
+        if ((tid & 63) == 0) {
+            sh.neq[tid >> 6] = neq;
+            sh.lit[tid >> 6] = 0;
+            sh.ms[tid >> 6] = 0;
+            sh.ins[tid >> 6] = 0;
+            sh.slow[tid >> 6] = 0;
+        }
+    }
     __syncthreads();
 
     uint32_t A = (act ? GLZ_A_ACT : 0u) | (rle ? GLZ_A_RLE : 0u);
     uint32_t B = 0;
-    if (look) {
-        const int maxn = ip_bound - q;
-        uint32_t mine[GLZ_K];
-#pragma unroll
-        for (int k = 0; k < GLZ_K; k++) {
-            mine[k] = sh.tile[p + 1 + k] & T::MASK;
-        }
+    const int maxn = ip_bound - q;
 
-        /* the two nearest earlier positions with this hash */
-        int n1 = -1, n2 = -1;
-        bool more = false; /* a third one exists */
-        for (int v = p >> 5; v >= 0 && !more; v--) {
+    /* (1) the two nearest earlier window positions with this hash */
+    int n1 = -1, n2 = -1;
+    if (look) {
+        for (int v = p >> 5; v >= 0 && n2 < 0; v--) {
             uint32_t bits = row[v];
             if (v == (p >> 5)) {
                 bits &= (1u << (p & 31)) - 1;
             }
-            while (bits && !more) {
+            while (bits && n2 < 0) {
                 const int b = 31 - __clz((int)bits);
                 bits &= ~(1u << b);
                 const int j = v * 32 + b;
                 if (sh.hash[j] == h) {
                     if (n1 < 0) {
                         n1 = j;
-                    } else if (n2 < 0) {
-                        n2 = j;
                     } else {
-                        more = true;
+                        n2 = j;
                     }
                 }
             }
         }
-        A |= more ? GLZ_A_MORE : 0u;
-        if (n1 >= 0) {
-            int len = 0;
-            bool run = true;
-#pragma unroll
-            for (int k = 0; k < GLZ_K; k++) {
-                run = run && k < maxn && (sh.tile[n1 + 1 + k] & T::MASK) == mine[k];
-                len += run ? 1 : 0;
-            }
-            const bool maxed = len == GLZ_K && GLZ_K < maxn;
-            A |= GLZ_A_P1V | ((n1 >> 6) == (p >> 6) ? GLZ_A_P1SAME : 0u) | ((uint32_t)n1 << GLZ_A_P1_SHIFT) |
-                 ((uint32_t)glz_accept_near<MODE>(len) << GLZ_A_LEN1_SHIFT) | (maxed ? GLZ_A_MAX1 : 0u);
-        }
-        if (n2 >= 0) {
-            int len = 0;
-            bool run = true;
-#pragma unroll
-            for (int k = 0; k < GLZ_K; k++) {
-                run = run && k < maxn && (sh.tile[n2 + 1 + k] & T::MASK) == mine[k];
-                len += run ? 1 : 0;
-            }
-            const bool maxed = len == GLZ_K && GLZ_K < maxn;
-            A |= GLZ_A_P2V | ((n2 >> 6) == (p >> 6) ? GLZ_A_P2SAME : 0u);
-            B = (uint32_t)n2 | ((uint32_t)glz_accept_near<MODE>(len) << GLZ_B_LEN2_SHIFT) |
-                (maxed ? GLZ_B_MAX2 : 0u);
-        }
+    }
 
-        /* the table's entry: validation + do_match (glz_encode_tmpl.c:147-262) */
+    /* (2) the table's entry: validation and do_match's distance rules
+     * (glz_encode_tmpl.c:147-229); its pixels are requested here and compared
+     * in (4) */
+    bool gok = false, capped = false;
+    int maxk = 0;
+    uint32_t gidist = 0, gpdist = 0;
+    uint32_t r[GLZ_K];
+#pragma unroll
+    for (int k = 0; k < GLZ_K; k++) {
+        r[k] = 0;
+    }
+    if (look) {
         const GlzDevSeg rs = glz_seg(job, sh, he.x);
         const bool valid =
             he.x == seg_idx ||
@@ -787,52 +757,107 @@ __device__ __forceinline__ void glz_window_scan(const GlzDevJob &job, const GlzD
             if (pdist != 0 && pdist < 33554432ull && idist <= 16777215ull) {
                 const GLZ_GLOBAL uint8_t *rbase = glz_arena(job) + (size_t)rs.arena_off16 * 16;
                 const int ref = (int)he.y;
-                int maxk = maxn;
                 const int rmax = (int)rs.nunits - ref;
-                maxk = rmax < maxk ? rmax : maxk;
-                const bool capped = maxk > GLZ_K;
+                maxk = rmax < maxn ? rmax : maxn;
+                capped = maxk > GLZ_K;
                 maxk = capped ? GLZ_K : maxk;
-                uint32_t r[GLZ_K];
+                gok = true;
+                gidist = (uint32_t)idist;
+                gpdist = (uint32_t)pdist;
 #pragma unroll
                 for (int k = 0; k < GLZ_K; k++) {
-                    r[k] = glz_load_px<MODE>(rbase, ref + (k < maxk ? k : 0)) & T::MASK;
-                }
-                int len = 0;
-                bool run = true;
-#pragma unroll
-                for (int k = 0; k < GLZ_K; k++) {
-                    run = run && k < maxk && r[k] == mine[k];
-                    len += run ? 1 : 0;
-                }
-                if (len >= T::MIN_REF && len <= T::MAX_REF) {
-                    /* glz_encode_tmpl.c:243-261 */
-                    const int need = glz_ref_bytes((uint32_t)idist, (uint32_t)pdist) / T::ENC_DIV + 1;
-                    if (len < need) {
-                        len = 0;
-                    }
-                }
-                if (len >= T::MIN_REF) {
-                    A |= ((uint32_t)len << GLZ_A_GLEN_SHIFT) | (capped && len == GLZ_K ? GLZ_A_GMAX : 0u);
-                    sh.g_ref[p] = he.y;
-                    sh.g_seg[p] = he.x;
-                    sh.g_idist[p] = (uint32_t)idist;
-                    sh.g_pdist[p] = (uint32_t)pdist;
+                    r[k] = glz_load_px<MODE>(rbase, ref + (k < maxk ? k : 0));
                 }
             }
         }
     }
-    sh.infoA[p] = A;
-    sh.infoB[p] = B;
-    {
-        const uint64_t neq = __ballot(c0 != cm1);
-        if ((tid & 63) == 0) {
-            sh.neq[tid >> 6] = neq;
-            sh.lit[tid >> 6] = 0;
-            sh.ms[tid >> 6] = 0;
-            sh.ins[tid >> 6] = 0;
-            sh.slow[tid >> 6] = 0;
+
+    /* (3) the window candidates against the LDS tile */
+    uint32_t mine[GLZ_K];
+#pragma unroll
+    for (int k = 0; k < GLZ_K; k++) {
+        mine[k] = sh.tile[p + 1 + k] & T::MASK;
+    }
+    if (n1 >= 0) {
+        int len = 0;
+        bool run = true;
+#pragma unroll
+        for (int k = 0; k < GLZ_K; k++) {
+            run = run && k < maxn && (sh.tile[n1 + 1 + k] & T::MASK) == mine[k];
+            len += run ? 1 : 0;
+        }
+        const bool maxed = len == GLZ_K && GLZ_K < maxn;
+        A |= GLZ_A_P1V | ((n1 >> 6) == (p >> 6) ? GLZ_A_P1SAME : 0u) | ((uint32_t)n1 << GLZ_A_P1_SHIFT) |
+             ((uint32_t)glz_accept_near<MODE>(len) << GLZ_A_LEN1_SHIFT) | (maxed ? GLZ_A_MAX1 : 0u);
+    }
+    if (n2 >= 0) {
+        int len = 0;
+        bool run = true;
+#pragma unroll
+        for (int k = 0; k < GLZ_K; k++) {
+            run = run && k < maxn && (sh.tile[n2 + 1 + k] & T::MASK) == mine[k];
+            len += run ? 1 : 0;
+        }
+        const bool maxed = len == GLZ_K && GLZ_K < maxn;
+        /* a third position with this hash is not looked for: take it that one exists */
+        A |= GLZ_A_P2V | GLZ_A_MORE | ((n2 >> 6) == (p >> 6) ? GLZ_A_P2SAME : 0u);
+        B = (uint32_t)n2 | ((uint32_t)glz_accept_near<MODE>(len) << GLZ_B_LEN2_SHIFT) |
+            (maxed ? GLZ_B_MAX2 : 0u);
+    }
+
+    /* (4) the table's candidate */
+    if (gok) {
+        int len = 0;
+        bool run = true;
+#pragma unroll
+        for (int k = 0; k < GLZ_K; k++) {
+            run = run && k < maxk && (r[k] & T::MASK) == mine[k];
+            len += run ? 1 : 0;
+        }
+        if (len >= T::MIN_REF && len <= T::MAX_REF) {
+            /* glz_encode_tmpl.c:243-261 */
+            const int need = glz_ref_bytes(gidist, gpdist) / T::ENC_DIV + 1;
+            if (len < need) {
+                len = 0;
+            }
+        }
+        if (len >= T::MIN_REF) {
+            A |= ((uint32_t)len << GLZ_A_GLEN_SHIFT) | (capped && len == GLZ_K ? GLZ_A_GMAX : 0u);
+            sh.g_ref[p] = he.y;
+            sh.g_seg[p] = he.x;
+            sh.g_idist[p] = gidist;
+            sh.g_pdist[p] = gpdist;
         }
     }
+    if (rle) {
+        /* glz_encode_tmpl.c:310-335: the run ends at the first pixel that
+         * differs from its predecessor; B = its length, 0 when it leaves the
+         * window (glz_resolve_general measures those) */
+        const int from = p + 3, fw = from >> 6;
+        const uint64_t keep = ~0ull << (from & 63);
+        const uint64_t q0 = sh.neq[0], q1 = sh.neq[1], q2 = sh.neq[2], q3 = sh.neq[3];
+        const uint64_t m0 = fw == 0 ? q0 & keep : 0ull;
+        const uint64_t m1 = fw == 1 ? q1 & keep : (fw < 1 ? q1 : 0ull);
+        const uint64_t m2 = fw == 2 ? q2 & keep : (fw < 2 ? q2 : 0ull);
+        const uint64_t m3 = fw == 3 ? q3 & keep : (fw < 3 ? q3 : 0ull);
+        int j = GLZ_WIN;
+        if (m0) {
+            j = __ffsll((unsigned long long)m0) - 1;
+        } else if (m1) {
+            j = 64 + __ffsll((unsigned long long)m1) - 1;
+        } else if (m2) {
+            j = 128 + __ffsll((unsigned long long)m2) - 1;
+        } else if (m3) {
+            j = 192 + __ffsll((unsigned long long)m3) - 1;
+        }
+        if (fw <= 3 && j < GLZ_WIN) {
+            int end = ip + j;
+            end = end < ip_bound ? end : ip_bound;
+            B = (uint32_t)(end - q);
+        }
+    }
+    sh.infoA[p] = A;
+    sh.infoB[p] = B;
 }
 
 /* stores of one match's tail (window positions t0, t1; -1 = none) that fall into quarter q */
@@ -856,7 +881,8 @@ __device__ __forceinline__ uint64_t glz_tail_bits(int t0, int t1, int q)
 #define GLZ_W_L1_SHIFT 12     /* 5 bits each: accepted length, or a GLZ_W_LEN_* code */
 #define GLZ_W_L2_SHIFT 17
 #define GLZ_W_LF_SHIFT 22
-#define GLZ_W_SLOW 0x80000000u /* not an ordinary stop: no stop here, or the run test succeeds */
+#define GLZ_W_SLOW 0x80000000u /* no stop here, or a run that leaves the window */
+#define GLZ_W_RUN 0x40000000u  /* the run test succeeds; the low bits hold the run's length */
 #define GLZ_W_LEN_MAXED 30     /* the compare has to go on past GLZ_K */
 #define GLZ_W_LEN_DEEP 31      /* an older store to the slot may exist */
 
@@ -867,8 +893,11 @@ __device__ __forceinline__ uint32_t glz_quarter_words(int Q, int lane)
     const uint32_t *ins32 = (const uint32_t *)sh.ins;
     const int p = Q * 64 + lane;
     const uint32_t a = sh.infoA[p], b = sh.infoB[p];
-    if (!(a & GLZ_A_ACT) || (a & GLZ_A_RLE)) {
+    if (!(a & GLZ_A_ACT)) {
         return GLZ_W_SLOW;
+    }
+    if (a & GLZ_A_RLE) {
+        return b ? GLZ_W_RUN | b : GLZ_W_SLOW; /* a run that leaves the window: glz_resolve_general */
     }
     uint32_t d1 = (uint32_t)lane, d2 = (uint32_t)lane, l1 = 0, l2 = 0;
     uint32_t lf = (a & GLZ_A_GMAX) ? GLZ_W_LEN_MAXED : (a >> GLZ_A_GLEN_SHIFT) & 31u;
@@ -902,6 +931,114 @@ __device__ __forceinline__ uint32_t glz_quarter_words(int Q, int lane)
         }
     }
     return d1 | (d2 << GLZ_W_D2_SHIFT) | (l1 << GLZ_W_L1_SHIFT) | (l2 << GLZ_W_L2_SHIFT) | (lf << GLZ_W_LF_SHIFT);
+}
+
+/* The walk over the ordinary stops of a quarter, from position l on: picks the
+ * length (the candidate at d1 if that position was stored, else the one at d2
+ * if stored, else the fall-back), marks the stop, its store and, for a match,
+ * the stores of its last two positions (glz_encode_tmpl.c:381,424-444: for
+ * every pixel type a match of 2 stores one position, a longer one two), and
+ * moves on.  Returns at the quarter's end (l >= 64) or at a stop that needs
+ * glz_resolve_general.  A wavefront runs this at one instruction per ~5
+ * cycles, so the loop is written out instruction by instruction. */
+__device__ __forceinline__ void glz_fast_stops(uint32_t W, int &l, uint64_t &ins, uint64_t &stops,
+                                               uint64_t &ms, int &last_len)
+{
+#ifdef SPICE_WAVE_SIM
+    while (l < 64) {
+        const uint32_t w = glz_readlane(W, l);
+        if (w & GLZ_W_SLOW) {
+            break;
+        }
+        const uint64_t bit = 1ull << l;
+        int len;
+        if (w & GLZ_W_RUN) {
+            len = (int)(w & 0x1ffu); /* a run stores nothing at its first position */
+        } else {
+            const int d1 = (int)(w & 63u), d2 = (int)((w >> GLZ_W_D2_SHIFT) & 63u);
+            len = ((ins >> d2) & 1) ? (int)((w >> GLZ_W_L2_SHIFT) & 31u) : (int)((w >> GLZ_W_LF_SHIFT) & 31u);
+            len = ((ins >> d1) & 1) ? (int)((w >> GLZ_W_L1_SHIFT) & 31u) : len;
+            if (len >= GLZ_W_LEN_MAXED) {
+                break;
+            }
+            ins |= bit;
+        }
+        stops |= bit;
+        if (len == 0) {
+            l++;
+        } else {
+            const uint64_t tm = len > 2 ? 3ull : 2ull;
+            const int sh0 = l + len - 2;
+            ms |= bit;
+            ins |= sh0 < 64 ? tm << sh0 : 0ull;
+            l += len;
+        }
+        last_len = len;
+    }
+#else
+    uint32_t w, len, t;
+    uint64_t bit, tm;
+    /* the operands below live in scalar registers; every lane holds the same values */
+    l = (int)glz_uniform((uint32_t)l);
+    last_len = (int)glz_uniform((uint32_t)last_len);
+    ins = glz_uniform64(ins);
+    stops = glz_uniform64(stops);
+    ms = glz_uniform64(ms);
+    asm volatile(
+        "s_cmp_lt_i32 %[l], 64\n"
+        "s_cbranch_scc0 9f\n"
+        "1:\n"
+        "s_nop 3\n"                                /* l was just written; it selects the lane */
+        "v_readlane_b32 %[w], %[W], %[l]\n"
+        "s_cmp_ge_u32 %[w], 0x40000000\n"
+        "s_cbranch_scc1 3f\n"                      /* GLZ_W_SLOW or GLZ_W_RUN */
+        "s_lshr_b32 %[t], %[w], 6\n"
+        "s_bitcmp1_b64 %[ins], %[t]\n"             /* bit index = low six bits: d2 */
+        "s_cselect_b32 %[t], 17, 22\n"
+        "s_bitcmp1_b64 %[ins], %[w]\n"             /* d1 */
+        "s_cselect_b32 %[t], 12, %[t]\n"
+        "s_lshr_b32 %[len], %[w], %[t]\n"
+        "s_and_b32 %[len], %[len], 31\n"
+        "s_cmp_gt_u32 %[len], 29\n"
+        "s_cbranch_scc1 9f\n"                      /* GLZ_W_LEN_MAXED, GLZ_W_LEN_DEEP */
+        "s_lshl_b64 %[bit], 1, %[l]\n"
+        "s_or_b64 %[stops], %[stops], %[bit]\n"
+        "s_or_b64 %[ins], %[ins], %[bit]\n"
+        "s_mov_b32 %[last], %[len]\n"
+        "s_cmp_eq_u32 %[len], 0\n"
+        "s_cbranch_scc1 2f\n"
+        "4:\n"
+        "s_or_b64 %[ms], %[ms], %[bit]\n"
+        "s_cmp_gt_u32 %[len], 2\n"
+        "s_cselect_b64 %[tm], 3, 2\n"
+        "s_add_i32 %[l], %[l], %[len]\n"
+        "s_add_i32 %[t], %[l], -2\n"
+        "s_lshl_b64 %[tm], %[tm], %[t]\n"
+        "s_cmp_lt_i32 %[t], 64\n"
+        "s_cselect_b64 %[tm], %[tm], 0\n"
+        "s_or_b64 %[ins], %[ins], %[tm]\n"
+        "s_cmp_lt_i32 %[l], 64\n"
+        "s_cbranch_scc1 1b\n"
+        "s_branch 9f\n"
+        "2:\n"
+        "s_add_i32 %[l], %[l], 1\n"
+        "s_cmp_lt_i32 %[l], 64\n"
+        "s_cbranch_scc1 1b\n"
+        "s_branch 9f\n"
+        "3:\n"                                     /* a run: no store at the stop itself */
+        "s_cmp_lt_i32 %[w], 0\n"
+        "s_cbranch_scc1 9f\n"
+        "s_and_b32 %[len], %[w], 0x1ff\n"
+        "s_lshl_b64 %[bit], 1, %[l]\n"
+        "s_or_b64 %[stops], %[stops], %[bit]\n"
+        "s_mov_b32 %[last], %[len]\n"
+        "s_branch 4b\n"
+        "9:\n"
+        : [l] "+s"(l), [ins] "+s"(ins), [stops] "+s"(stops), [ms] "+s"(ms), [last] "+s"(last_len),
+          [w] "=&s"(w), [len] "=&s"(len), [t] "=&s"(t), [bit] "=&s"(bit), [tm] "=&s"(tm)
+        : [W] "v"(W)
+        : "scc");
+#endif
 }
 
 /* The stops that need more than the quarter word: runs, compares that go on
@@ -1048,7 +1185,6 @@ __device__ __forceinline__ void glz_window_resolve(const GlzDevJob &job, uint32_
 
     while (open && i < GLZ_WIN) {
         const int Q = i >> 6;
-        unsigned long long tqa = PROF_T();
         /* quarters a match jumped over hold nothing but its tail's stores */
         for (int q = qnext; q < Q; q++) {
             const uint64_t m = glz_tail_bits(t0, t1, q);
@@ -1060,52 +1196,41 @@ __device__ __forceinline__ void glz_window_resolve(const GlzDevJob &job, uint32_
         uint64_t ins = glz_tail_bits(t0, t1, Q), stops = 0, ms = 0, slow = 0;
         __builtin_amdgcn_wave_barrier(); /* lane 0's marks of the finished quarters are read below */
         const uint32_t W = glz_quarter_words<MODE>(Q, lane);
+        sh.qword[Q * 64 + lane] = W;
         int l = i & 63;
         int last_len = 0;
-        unsigned long long tqb = PROF_T();
-        PROF_ADD(6, tqb - tqa); PROF_ADD(7, 1);
 
         while (l < 64) {
-            const uint32_t w = glz_readlane(W, l);
-            const uint64_t bit = 1ull << l;
-            int len;
-            bool general = w & GLZ_W_SLOW;
-            if (!general) {
-                const int d1 = (int)(w & 63u), d2 = (int)((w >> GLZ_W_D2_SHIFT) & 63u);
-                len = ((ins >> d2) & 1) ? (int)((w >> GLZ_W_L2_SHIFT) & 31u) : (int)((w >> GLZ_W_LF_SHIFT) & 31u);
-                len = ((ins >> d1) & 1) ? (int)((w >> GLZ_W_L1_SHIFT) & 31u) : len;
-                general = len >= GLZ_W_LEN_MAXED;
+            /* ordinary stops: everything needed is in the quarter word */
+            glz_fast_stops(W, l, ins, stops, ms, last_len);
+            if (l >= 64) {
+                break;
             }
-            bool own = true;
-            if (general) {
-                if (!(glz_uniform(sh.infoA[Q * 64 + l]) & GLZ_A_ACT)) {
-                    open = false; /* the segment's last stops are behind us */
-                    break;
-                }
-                bool run;
-                unsigned long long tg_ = PROF_T();
-                len = glz_resolve_general<MODE>(job, base, ip, ip_bound, Q * 64 + l, ins, vfl, q0, q1, q2, q3,
-                                                lane, &run);
-                PROF_ADD(8, 1); PROF_ADD(9, PROF_T() - tg_);
-                own = !run;
-                slow |= bit;
+            /* the others: no stop here at all, a run, a compare that goes on
+             * past GLZ_K, a slot whose nearest two predecessors were skipped */
+            if (!(glz_uniform(sh.infoA[Q * 64 + l]) & GLZ_A_ACT)) {
+                open = false; /* the segment's last stops are behind us */
+                break;
             }
-            /* the stop stored its position unless it was a run (glz_encode_tmpl.c:381) */
-            ins |= own ? bit : 0;
-            stops |= bit;
-            ms |= len ? bit : 0;
-            /* the two positions stored after a match, glz_encode_tmpl.c:424-444 */
             {
-                const uint64_t tm = len ? ((!T::GUARD_A || len > 2 ? 1ull : 0ull) | (!T::GUARD_B || len > 1 ? 2ull : 0ull)) : 0ull;
-                const int sh0 = l + len - 2;
-                ins |= sh0 < 64 ? (sh0 >= 0 ? tm << sh0 : tm >> 1) : 0ull;
+                const uint64_t bit = 1ull << l;
+                bool run;
+                const int len = glz_resolve_general<MODE>(job, base, ip, ip_bound, Q * 64 + l, ins, vfl, q0, q1,
+                                                          q2, q3, lane, &run);
+                slow |= bit;
+                stops |= bit;
+                ins |= run ? 0ull : bit;
+                if (len) {
+                    const uint64_t tm = (!T::GUARD_A || len > 2 ? 1ull : 0ull) | (!T::GUARD_B || len > 1 ? 2ull : 0ull);
+                    const int sh0 = l + len - 2;
+                    ms |= bit;
+                    ins |= sh0 < 64 ? tm << sh0 : 0ull;
+                }
+                last_len = len;
+                l += len ? len : 1;
             }
-            last_len = len;
-            l += len ? len : 1;
         }
 
-        unsigned long long tqc = PROF_T();
-        PROF_ADD(10, tqc - tqb);
         i = Q * 64 + l;
         t0 = t1 = -1;
         if (open && last_len) {
@@ -1126,7 +1251,6 @@ __device__ __forceinline__ void glz_window_resolve(const GlzDevJob &job, uint32_
         }
         vfl |= (uint32_t)((ins >> lane) & 1) << Q;
         qnext = Q + 1;
-        PROF_ADD(11, PROF_T() - tqc);
     }
     /* quarters behind the last one walked: only tail stores can be in them */
     for (int q = qnext; q < 4; q++) {
@@ -1279,6 +1403,8 @@ __device__ __forceinline__ void glz_window_emit(const GlzDevJob &job, uint32_t s
         uint32_t tok;
         if ((sh.slow[p >> 6] >> lane) & 1) {
             tok = sh.tok[p];
+        } else if (a & GLZ_A_RLE) {
+            tok = (sh.qword[p] & 0x1ffu) | (GLZ_SEL_RUN << 29);
         } else if ((a & GLZ_A_P1V) && ((ins32[n1 >> 5] >> (n1 & 31u)) & 1u)) {
             /* the same choice wavefront 0 made, now that every store is known */
             tok = ((a >> GLZ_A_LEN1_SHIFT) & 31u) | (GLZ_SEL_P1 << 29);
@@ -1375,27 +1501,21 @@ __device__ __forceinline__ void glz_parse_seg(const GlzDevJob &job, uint32_t seg
     int ip = from;
 
     while (ip < ip_limit) {
-        unsigned long long ta = PROF_T();
         for (int t = tid; t < GLZ_TILE; t += GLZ_THREADS) {
             const int pos = ip - 1 + t;
             sh.tile[t] = (pos >= 0 && pos < npix) ? glz_load_px<MODE>(base, pos) : 0u;
         }
         __syncthreads();
-        unsigned long long tb = PROF_T();
         uint32_t my_h;
         bool my_hv;
         glz_window_scan<MODE>(job, cs, seg_idx, base, ip, npix, tid, my_h, my_hv);
         __syncthreads();
-        unsigned long long tc = PROF_T();
         if (w0) {
             glz_window_resolve<MODE>(job, seg_idx, base, ip, npix, lane);
         }
         __syncthreads();
-        unsigned long long td = PROF_T();
         glz_window_emit<MODE>(job, seg_idx, ip, tid, my_h, my_hv);
         __syncthreads();
-        unsigned long long te = PROF_T();
-        PROF_ADD(0, tb - ta); PROF_ADD(1, tc - tb); PROF_ADD(2, td - tc); PROF_ADD(3, te - td); PROF_ADD(4, 1);
         ip = sh.next_ip;
     }
 
@@ -1461,11 +1581,6 @@ glz_parse_kernel(const GlzDevJob *__restrict__ jobs, const uint32_t *__restrict_
     }
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
-#ifdef GLZ_PROFILE
-    if (tid < 32) {
-        glz_prof_sh[tid] = 0;
-    }
-#endif
 
     for (uint32_t u = (uint32_t)tid; u < job.nupd; u += GLZ_THREADS) {
         const GlzDevSegUpdate up = upd_pool[job.upd_off + u];
@@ -1524,11 +1639,6 @@ glz_parse_kernel(const GlzDevJob *__restrict__ jobs, const uint32_t *__restrict_
         }
     }
     __syncthreads();
-#ifdef GLZ_PROFILE
-    if (tid < 32 && blockIdx.x == 0) {
-        glz_prof[tid] += glz_prof_sh[tid];
-    }
-#endif
     if (tid == 0) {
         const uint32_t op = sh.op;
         *job.result = op > job.out_cap ? GLZ_DEV_ERR_NO_SPACE : (int32_t)op;
