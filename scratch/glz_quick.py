@@ -2,7 +2,10 @@ import sys, time, numpy as np
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import spice_amd
 from spice_amd import binding as B, frames
-gpu=spice_amd.load(0)
+import ctypes
+gpu=B.SpiceGpu(ctypes.CDLL(os.environ['GLZ_LIB'])) if os.environ.get('GLZ_LIB') else None
+if gpu: gpu.init(0)
+else: gpu=spice_amd.load(0)
 S=int(sys.argv[1]) if len(sys.argv)>1 else 16
 NF=int(sys.argv[2]) if len(sys.argv)>2 else 6
 W,H=1920,1080
