@@ -34,6 +34,18 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E, datasheet
 
 
+def pmc_traffic(workload, key, value):
+    """HBM bytes per launch of the workload's dominant kernel, from the PMC passes kept under
+    profiles/ (rocprofv3 cannot run inside this process); None when they were taken on another
+    configuration."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            t = json.load(f)[workload]
+        return int(t["traffic_bytes"]) if t.get(key) == value else None
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -115,8 +127,8 @@ class GlzWorkload:
         ach = alg / avg_s / 1e9
         r = {"bound": "hbm", "kernel": "glz_parse_kernel", "achieved": round(ach, 2),
              "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5),
-             "traffic": None, "avg_launch_ms": round(ms / launches, 3),
-             "algorithmic_bytes_per_launch": int(alg)}
+             "traffic": pmc_traffic("glz1080", "sessions_per_gpu", self.S),
+             "avg_launch_ms": round(ms / launches, 3), "algorithmic_bytes_per_launch": int(alg)}
         cl, cms = times.get("glz_copy_kernel", (0, 0.0))
         if cl:
             calg = self.S * W1080 * H1080 * 8
@@ -138,9 +150,13 @@ class GlzWorkload:
         O.lib()
         dicts = [O.GlzDict(GLZ_WINDOW, 1) for _ in range(threads)]
 
+        own = [0.0] * threads
+
         def work(t):
+            t1 = time.time()
             for f in seqs[t]:
                 dicts[t].encode(O.TYPE_RGB32, W1080, H1080, W1080 * 4, [f])
+            own[t] = time.time() - t1
 
         ths = [threading.Thread(target=work, args=(t,)) for t in range(threads)]
         t0 = time.time()
@@ -149,8 +165,9 @@ class GlzWorkload:
         for th in ths:
             th.join()
         dt = time.time() - t0
+        one = nfr * W1080 * H1080 / (sum(own) / threads) / 1e6
         return {"value": round(threads * nfr * W1080 * H1080 / dt / 1e6, 1), "unit": "Mpixels/s",
-                "cores": threads, "kind": "port",
+                "cores": threads, "kind": "port", "per_core": round(one, 1),
                 "sample": "%d sessions x %d 1920x1080 desktop frames through the CPU oracle "
                           "(oracle/glz_oracle.c), one thread per session, %.1f s wall" % (threads, nfr, dt)}
 
@@ -207,8 +224,8 @@ class MjpegWorkload:
         ach = alg / avg_s / 1e9
         r = {"bound": "hbm", "kernel": "jpeg_strip_kernel_ifast", "achieved": round(ach, 2),
              "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5),
-             "traffic": None, "avg_launch_ms": round(ms / launches, 3),
-             "algorithmic_bytes_per_launch": int(alg)}
+             "traffic": pmc_traffic("mjpeg2160", "frames_per_step_per_gpu", self.F),
+             "avg_launch_ms": round(ms / launches, 3), "algorithmic_bytes_per_launch": int(alg)}
         tail = sum(times.get(k, (0, 0.0))[1] for k in
                    ("jpeg_offsets_kernel", "jpeg_gather_kernel", "jpeg_finish_kernel"))
         r["bitstream_kernels_ms_per_launch"] = round(tail / launches, 3)
