@@ -90,6 +90,30 @@ def run_plumbing(dev, oracle):
         pair.close()
 
 
+def run_low_entropy(dev, oracle, typ, nimages, w, h):
+    """Few colours in short random runs: nearly every 3-pixel hash recurs many
+    times inside a 256-position window, so table slots are overwritten by
+    stops, by match tails and -- for skipped positions -- not at all; runs of
+    every length from 3 pixels to several windows."""
+    rng = np.random.default_rng(1000 + typ)
+    pair = GlzPair(dev, oracle, w * h * 3)
+    try:
+        for i in range(nimages):
+            ncol = 2 + i % 4
+            palette = rng.integers(0, 256, (ncol, 3))
+            mean_run = (1.5, 3.0, 8.0, 40.0, 700.0)[i % 5]
+            runs = rng.geometric(1.0 / mean_run, size=w * h)
+            idx = np.repeat(rng.integers(0, ncol, size=runs.size), runs)[: w * h]
+            im = np.zeros((h * w, 4), np.uint8)
+            im[:, :3] = palette[idx]
+            if i % 3 == 2:  # a periodic stretch: matches at distance < 64 that go on for long
+                im[w * 3 : w * 9] = im[w * 3 + np.arange(w * 6) % 37]
+            px = pixels_for(typ, im.reshape(h, w, 4), rng)
+            pair.encode(typ, w, h, px.shape[1], split_rows(px, 1 + i % 2), what="low entropy %d" % i)
+    finally:
+        pair.close()
+
+
 # ------------------------------------------------------------------ CPU (sim)
 @pytest.mark.parametrize("typ", TYPES)
 def test_sim_mixed_sequence(sim, oracle, typ):
@@ -99,6 +123,11 @@ def test_sim_mixed_sequence(sim, oracle, typ):
 @pytest.mark.parametrize("typ", [B.LZ_IMAGE_TYPE_RGB32, B.LZ_IMAGE_TYPE_RGBA, B.LZ_IMAGE_TYPE_RGB16])
 def test_sim_noise_and_runs(sim, oracle, typ):
     run_noise_and_runs(sim, oracle, typ)
+
+
+@pytest.mark.parametrize("typ", TYPES)
+def test_sim_low_entropy(sim, oracle, typ):
+    run_low_entropy(sim, oracle, typ, 10, 173, 29)
 
 
 def test_sim_desktop_frames(sim, oracle):
@@ -120,6 +149,12 @@ def test_gpu_mixed_sequence(gpu, oracle, typ):
 @pytest.mark.parametrize("typ", TYPES)
 def test_gpu_noise_and_runs(gpu, oracle, typ):
     run_noise_and_runs(gpu, oracle, typ)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("typ", TYPES)
+def test_gpu_low_entropy(gpu, oracle, typ):
+    run_low_entropy(gpu, oracle, typ, 20, 640, 97)
 
 
 @pytest.mark.gpu
