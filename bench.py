@@ -263,6 +263,45 @@ class MjpegWorkload:
                              if use_ref else "oracle/jpeg_oracle.c", dt)}
 
 
+def graduality_line(gpu, mj, args):
+    """The codec-choice scorer (_get_bitmap_graduality_level) over the MJPEG workload's frames."""
+    from spice_amd import binding as B
+    n, reps = 64, 10
+    items = [dict(format=B.BITMAP_FMT_32BIT, width=W2160, chunks=[(mj.dev_frames[k % mj.pool], H2160)])
+             for k in range(n)]
+    B.graduality_batch(gpu, items)
+    gpu.L.spice_gpu_timing_enable(1)
+    gpu.L.spice_gpu_timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        res = B.graduality_batch(gpu, items)
+    dt = time.perf_counter() - t0
+    gpu.L.spice_gpu_timing_enable(0)
+    launches, ms = gpu.kernel_times().get("gradual_kernel", (0, 0.0))
+    samples = sum(r[2] for r in res) // 3
+    alg = samples * 16  # four 4-byte pixels per sample; sums stay in registers
+    line = {"workload": "graduality of %d 3840x2160 BGRX bitmaps per call (red_worker.c:5913-5967)" % n,
+            "value": round(n * reps * W2160 * H2160 / dt / 1e6, 1), "unit": "Mpixels/s"}
+    if launches:
+        ach = alg / (ms / launches / 1e3) / 1e9
+        line["roofline"] = {"bound": "hbm", "kernel": "gradual_kernel", "achieved": round(ach, 2),
+                            "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5),
+                            "traffic": None, "avg_launch_ms": round(ms / launches, 3),
+                            "algorithmic_bytes_per_launch": int(alg)}
+    if not args.no_cpu_baseline:
+        from oracle import oracle as O
+        f = mj.host_frames[0].reshape(H2160, -1)
+        t0 = time.time()
+        k = 0
+        while time.time() - t0 < 2.0:
+            O.graduality(O.FMT_32BIT, W2160, [f])
+            k += 1
+        line["cpu_baseline"] = {"value": round(k * W2160 * H2160 / (time.time() - t0) / 1e6, 1),
+                                "unit": "Mpixels/s", "cores": 1, "kind": "port",
+                                "sample": "%d 3840x2160 bitmaps through oracle/gradual_oracle.c, one thread" % k}
+    return line
+
+
 def run_workload(cls, gpu, dist, args, steps, warmup):
     wl = cls(gpu, args, dist.rank)
     for _ in range(warmup):
@@ -341,7 +380,7 @@ def main():
                     "roofline": wl2.roofline(times2, max(2, args.steps // 2), out2)}
             if not args.no_cpu_baseline:
                 also["cpu_baseline"] = wl2.cpu_baseline(args)
-            result["also"] = {"mjpeg2160": also}
+            result["also"] = {"mjpeg2160": also, "graduality2160": graduality_line(gpu, wl2, args)}
 
     if dist.rank == 0:
         print(json.dumps(result), flush=True)

@@ -275,6 +275,85 @@ int spice_gpu_jpeg_encode_batch(SpiceGpuJpegJob *jobs, int njobs);
 int spice_gpu_jpeg_submit(SpiceGpuJpegJob *jobs, int njobs);
 int spice_gpu_jpeg_finish(SpiceGpuJpegJob *jobs, int njobs);
 
+/* ---- Section 3: what decides between the codecs ------------------------
+ *
+ * Graduality of a bitmap, _get_bitmap_graduality_level
+ * (server/red_worker.c:5904-5967) over red_bitmap_utils.h:43-147: every 15th
+ * pixel (14th when the width divides 15) of all rows but a chunk's last is
+ * compared with its right, lower and lower-right neighbours; a pair scores
+ * 0.5 (equal), 1.0 (a channel differs by >= 60, or >= 8 of 31 for 16 bpp) or
+ * -0.25; squares of four equal pixels count 0.  The mean over 3 x samples is
+ * compared with -0.03 (0 for 16 bpp) and 0.002.  Rows are taken as `width`
+ * pixels apart, as the reference does (it scores only bitmaps whose stride has
+ * no padding). */
+typedef enum {
+    BITMAP_GRADUAL_INVALID,
+    BITMAP_GRADUAL_NOT_AVAIL,
+    BITMAP_GRADUAL_LOW,
+    BITMAP_GRADUAL_MEDIUM,
+    BITMAP_GRADUAL_HIGH,
+} BitmapGradualType; /* server/red_worker.c:798-804 */
+
+#define SPICE_GPU_GRADUAL_MAX_CHUNKS 16
+
+typedef struct SpiceGpuGradualJob {
+    int format;                 /* SPICE_GPU_BITMAP_FMT_16BIT / 24BIT / 32BIT / RGBA */
+    int width;
+    int num_chunks;             /* <= SPICE_GPU_GRADUAL_MAX_CHUNKS */
+    const void *chunks[SPICE_GPU_GRADUAL_MAX_CHUNKS];   /* device pointers */
+    uint32_t chunk_rows[SPICE_GPU_GRADUAL_MAX_CHUNKS];
+    /* results */
+    int level;                  /* BitmapGradualType */
+    double score;               /* the reference's score, bit for bit */
+    int64_t score_quarters;     /* sum of the pair scores in units of 0.25 */
+    int64_t num_samples;
+} SpiceGpuGradualJob;
+
+/* Bitmaps resident in HBM, any number per call (one kernel launch). */
+int spice_gpu_graduality_batch(SpiceGpuGradualJob *jobs, int njobs);
+
+/* The reference's call shape: chunks in host memory.  Returns the level, or
+ * BITMAP_GRADUAL_INVALID on error. */
+BitmapGradualType spice_gpu_bitmap_graduality_level(int format, int width, int num_chunks,
+                                                    const uint8_t *const *chunks,
+                                                    const uint32_t *chunk_rows);
+
+/* red_compress_image's choice of codec (server/red_worker.c:6411-6525) as a
+ * pure function of what it looks at. */
+typedef enum {                  /* spice_image_compression_t, server/spice.h:469-477 */
+    SPICE_IMAGE_COMPRESS_INVALID = 0,
+    SPICE_IMAGE_COMPRESS_OFF = 1,
+    SPICE_IMAGE_COMPRESS_AUTO_GLZ = 2,
+    SPICE_IMAGE_COMPRESS_AUTO_LZ = 3,
+    SPICE_IMAGE_COMPRESS_QUIC = 4,
+    SPICE_IMAGE_COMPRESS_GLZ = 5,
+    SPICE_IMAGE_COMPRESS_LZ = 6,
+} spice_image_compression_t;
+
+typedef enum {
+    SPICE_GPU_CODEC_NONE = 0,           /* send the bitmap as it is (the reference returns FALSE) */
+    SPICE_GPU_CODEC_QUIC = 1,
+    SPICE_GPU_CODEC_JPEG = 2,
+    SPICE_GPU_CODEC_GLZ = 3,
+    SPICE_GPU_CODEC_LZ = 4,
+    SPICE_GPU_CODEC_NEEDS_GRADUALITY = -1, /* call again with the bitmap's graduality filled in */
+    SPICE_GPU_CODEC_ERROR = -2,
+} SpiceGpuCodec;
+
+typedef struct SpiceGpuCodecQuery {
+    int image_compression;      /* spice_image_compression_t of the worker */
+    int format;                 /* SPICE_GPU_BITMAP_FMT_* (SPICE_BITMAP_FMT_* numbering) */
+    uint32_t x, y, stride;
+    int chunks_unstable;        /* SPICE_CHUNKS_FLAGS_UNSTABLE */
+    int can_lossy;
+    int enable_jpeg;            /* display_channel->enable_jpeg */
+    int graduality;             /* drawable->copy_bitmap_graduality; BITMAP_GRADUAL_INVALID = not known */
+    uint32_t glz_dict_size;     /* glz_enc_dictionary_get_size() */
+    int glz_frozen;             /* dcc->glz_dict->migrate_freeze */
+} SpiceGpuCodecQuery;
+
+SpiceGpuCodec spice_gpu_choose_codec(const SpiceGpuCodecQuery *q);
+
 /* Plain device-memory helpers so that hosts without a HIP binding (the C
  * server, ctypes tests) can stage inputs and fetch results. */
 void *spice_gpu_malloc(size_t bytes);

@@ -71,6 +71,12 @@ def lib():
         L.jpgo_coefficients.restype = C.c_long
         L.jpgo_coefficients.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_long, C.c_int, C.c_int,
                                         C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+        L.grado_level.restype = C.c_int
+        L.grado_level.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32),
+                                  C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+        L.grado_choose.restype = C.c_int
+        L.grado_choose.argtypes = [C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int,
+                                   C.c_int, C.c_int, C.c_uint32, C.c_int]
         _lib = L
     return _lib
 
@@ -227,3 +233,21 @@ def ref_jpeg_encode(pixels, width, height, stride, fmt, quality, dct, fancy=0):
     if n < 0:
         raise RuntimeError("libjpeg reference failed")
     return out[:n].copy()
+
+
+# ------------------------------------------------------------- codec choice
+def graduality(fmt, width, chunks):
+    """(level, score, samples) of a bitmap given as a list of (rows, width * bpp) uint8 arrays."""
+    chunks = [np.ascontiguousarray(c, dtype=np.uint8) for c in chunks]
+    n = len(chunks)
+    ptrs = (C.c_void_p * n)(*[c.ctypes.data for c in chunks])
+    rows = (C.c_uint32 * n)(*[c.shape[0] for c in chunks])
+    score, samples = C.c_double(0), C.c_int64(0)
+    lvl = lib().grado_level(fmt, width, n, ptrs, rows, C.byref(score), C.byref(samples))
+    return lvl, score.value, samples.value
+
+
+def choose_codec(comp, fmt, x, y, stride, unstable, can_lossy, enable_jpeg, graduality_level,
+                 glz_dict_size, glz_frozen):
+    return lib().grado_choose(comp, fmt, x, y, stride, int(unstable), int(can_lossy), int(enable_jpeg),
+                              graduality_level, glz_dict_size, int(glz_frozen))

@@ -51,6 +51,29 @@ class SpiceGpuGlzJob(C.Structure):
                 ("out_size", C.c_int32), ("dict_image", C.c_void_p)]
 
 
+GRADUAL_MAX_CHUNKS = 16
+BITMAP_GRADUAL_INVALID, BITMAP_GRADUAL_NOT_AVAIL, BITMAP_GRADUAL_LOW, BITMAP_GRADUAL_MEDIUM, \
+    BITMAP_GRADUAL_HIGH = range(5)
+IMAGE_COMPRESS_OFF, IMAGE_COMPRESS_AUTO_GLZ, IMAGE_COMPRESS_AUTO_LZ, IMAGE_COMPRESS_QUIC, \
+    IMAGE_COMPRESS_GLZ, IMAGE_COMPRESS_LZ = range(1, 7)
+CODEC_NONE, CODEC_QUIC, CODEC_JPEG, CODEC_GLZ, CODEC_LZ = range(5)
+CODEC_NEEDS_GRADUALITY, CODEC_ERROR = -1, -2
+
+
+class SpiceGpuGradualJob(C.Structure):
+    _fields_ = [("format", C.c_int), ("width", C.c_int), ("num_chunks", C.c_int),
+                ("chunks", C.c_void_p * GRADUAL_MAX_CHUNKS), ("chunk_rows", C.c_uint32 * GRADUAL_MAX_CHUNKS),
+                ("level", C.c_int), ("score", C.c_double), ("score_quarters", C.c_int64),
+                ("num_samples", C.c_int64)]
+
+
+class SpiceGpuCodecQuery(C.Structure):
+    _fields_ = [("image_compression", C.c_int), ("format", C.c_int), ("x", C.c_uint32), ("y", C.c_uint32),
+                ("stride", C.c_uint32), ("chunks_unstable", C.c_int), ("can_lossy", C.c_int),
+                ("enable_jpeg", C.c_int), ("graduality", C.c_int), ("glz_dict_size", C.c_uint32),
+                ("glz_frozen", C.c_int)]
+
+
 class SpiceGpuJpegJob(C.Structure):
     _fields_ = [("pixels", C.c_void_p), ("format", C.c_int), ("width", C.c_int), ("height", C.c_int),
                 ("stride", C.c_long), ("quality", C.c_int), ("dct", C.c_int), ("out", C.c_void_p),
@@ -85,6 +108,7 @@ EXPORTS = [
     "spice_gpu_jpeg_submit", "spice_gpu_jpeg_finish", "spice_gpu_malloc", "spice_gpu_free",
     "spice_gpu_upload", "spice_gpu_download", "spice_gpu_get_stats", "spice_gpu_reset_stats",
     "spice_gpu_timing_enable", "spice_gpu_timing_reset", "spice_gpu_timing_read",
+    "spice_gpu_graduality_batch", "spice_gpu_bitmap_graduality_level", "spice_gpu_choose_codec",
 ]
 
 
@@ -477,3 +501,41 @@ def jpeg_encode_batch(gpu, items):
     if gpu.L.spice_gpu_jpeg_encode_batch(jobs, n) != 0:
         raise SpiceGpuError("jpeg batch: " + gpu.last_error())
     return [jobs[j].out_size for j in range(n)]
+
+
+def graduality_batch(gpu, items):
+    """Device-resident bitmaps; items are dicts with format, width, chunks (list of
+    (device pointer, rows)).  Returns a list of (level, score, samples, score_quarters)."""
+    n = len(items)
+    jobs = (SpiceGpuGradualJob * n)()
+    for j, it in enumerate(items):
+        jobs[j].format, jobs[j].width, jobs[j].num_chunks = it["format"], it["width"], len(it["chunks"])
+        for c, (ptr, rows) in enumerate(it["chunks"]):
+            jobs[j].chunks[c] = ptr
+            jobs[j].chunk_rows[c] = rows
+    gpu.L.spice_gpu_graduality_batch.restype = C.c_int
+    if gpu.L.spice_gpu_graduality_batch(jobs, n) != 0:
+        raise SpiceGpuError("graduality batch: " + gpu.last_error())
+    return [(jobs[j].level, jobs[j].score, jobs[j].num_samples, jobs[j].score_quarters) for j in range(n)]
+
+
+def bitmap_graduality_level(gpu, fmt, width, chunks):
+    """The reference's call shape: chunks are (rows, width * bpp) uint8 arrays in host memory."""
+    chunks = [np.ascontiguousarray(c, dtype=np.uint8) for c in chunks]
+    n = len(chunks)
+    ptrs = (C.c_void_p * n)(*[c.ctypes.data for c in chunks])
+    rows = (C.c_uint32 * n)(*[c.shape[0] for c in chunks])
+    gpu.L.spice_gpu_bitmap_graduality_level.restype = C.c_int
+    gpu.L.spice_gpu_bitmap_graduality_level.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lvl = gpu.L.spice_gpu_bitmap_graduality_level(fmt, width, n, ptrs, rows)
+    if lvl == BITMAP_GRADUAL_INVALID:
+        raise SpiceGpuError("graduality: " + gpu.last_error())
+    return lvl
+
+
+def choose_codec(gpu, comp, fmt, x, y, stride, unstable, can_lossy, enable_jpeg, graduality,
+                 glz_dict_size, glz_frozen):
+    q = SpiceGpuCodecQuery(comp, fmt, x, y, stride, int(unstable), int(can_lossy), int(enable_jpeg),
+                           graduality, glz_dict_size, int(glz_frozen))
+    gpu.L.spice_gpu_choose_codec.restype = C.c_int
+    return gpu.L.spice_gpu_choose_codec(C.byref(q))
