@@ -5,8 +5,9 @@
  *
  * Pipeline per batch of jobs:
  *   jpeg_strip_kernel   pixels -> YCbCr 4:2:0 in LDS -> DCT -> quantise ->
- *                       Huffman bits of up to JPEG_STRIP_MCUS MCUs, one
- *                       workgroup per strip; bits land in the strip's slot
+ *                       Huffman bits; a workgroup takes JPEG_GROUP_STRIPS strips
+ *                       of up to JPEG_STRIP_MCUS MCUs, the bits of each land in
+ *                       the strip's slot
  *   jpeg_offsets_kernel exclusive scan of the strips' bit counts
  *   jpeg_gather_kernel  concatenates the strips at bit granularity into the
  *                       unstuffed scan, counts 0xFF bytes per 4 KiB chunk
@@ -19,7 +20,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define JPEG_STRIP_MCUS 40            /* 40 MCUs + 1 halo MCU = 246 blocks <= 256 lanes */
+#define JPEG_STRIP_MCUS 10            /* MCUs whose bits one wavefront produces */
+#define JPEG_GROUP_STRIPS 4           /* strips per workgroup: 40 MCUs + 1 halo MCU = 246 blocks <= 256 lanes */
 #define JPEG_STRIP_THREADS 256
 #define JPEG_MCU_SLOT_BYTES 1280      /* >= 6 blocks x 1658 bits worst case */
 #define JPEG_CHUNK_BYTES 4096         /* unstuffed bytes per 0xFF-count chunk */

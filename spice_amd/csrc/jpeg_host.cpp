@@ -18,7 +18,7 @@
 
 using namespace spicegpu;
 
-void jpeg_launch(const JpegDevJob *jobs, int njobs, int max_strips, bool any_islow, bool any_ifast,
+void jpeg_launch(const JpegDevJob *jobs, int njobs, int max_groups, bool any_islow, bool any_ifast,
                  const uint32_t *huff, hipStream_t stream);
 
 namespace {
@@ -262,7 +262,7 @@ bool submit_locked(JpegFlight &f, std::vector<JpegDevJob> &jobs)
         return false;
     }
     size_t need = 0;
-    int max_strips = 0;
+    int max_groups = 0;
     bool any_islow = false, any_ifast = false;
     for (JpegDevJob &j : jobs) {
         j.strip_stride = JPEG_MCU_SLOT_BYTES * JPEG_STRIP_MCUS;
@@ -273,7 +273,8 @@ bool submit_locked(JpegFlight &f, std::vector<JpegDevJob> &jobs)
         need += align256(sizeof(uint64_t) * ((size_t)j.nstrips + 1));
         need += align256(j.scan_cap + 64);
         need += align256(sizeof(uint32_t) * j.nchunks_cap);
-        max_strips = j.nstrips > max_strips ? j.nstrips : max_strips;
+        const int groups = (j.strips_per_row + JPEG_GROUP_STRIPS - 1) / JPEG_GROUP_STRIPS * j.mcu_rows;
+        max_groups = groups > max_groups ? groups : max_groups;
         (j.dct ? any_ifast : any_islow) = true;
     }
     size_t jobs_bytes = align256(sizeof(JpegDevJob) * (size_t)n);
@@ -302,7 +303,7 @@ bool submit_locked(JpegFlight &f, std::vector<JpegDevJob> &jobs)
                "upload jpeg jobs")) {
         return false;
     }
-    jpeg_launch((const JpegDevJob *)f.staging.dev, n, max_strips, any_islow, any_ifast, f.d_huff, s);
+    jpeg_launch((const JpegDevJob *)f.staging.dev, n, max_groups, any_islow, any_ifast, f.d_huff, s);
     if (!check(hipGetLastError(), "jpeg launch")) {
         return false;
     }

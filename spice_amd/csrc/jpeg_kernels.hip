@@ -3,17 +3,22 @@
  * libjpeg configuration the reference selects (server/mjpeg_encoder.c:771-823:
  * JDCT_IFAST; server/jpeg_encoder.c:232-246: JDCT_ISLOW).
  *
- * jpeg_strip_kernel: one 256-lane workgroup per strip of up to 40 MCUs.
+ * jpeg_strip_kernel: one 256-lane workgroup per group of four strips (a strip
+ * is up to 10 MCUs of one MCU row, a group up to 40).
  *   phase 1  coalesced pixel reads (RGB16 / BGR24 / BGRX32 converters of
  *            server/mjpeg_encoder.c:236-259), libjpeg's fixed-point RGB->YCbCr,
  *            2x2 chroma box filter with the alternating 1,2 bias, edge
  *            replication exactly where libjpeg applies it; samples go to LDS
  *   phase 2  one lane per 8x8 block: the whole integer DCT (LL&M "islow" or
- *            AA&N "ifast") and the divide-with-rounding quantiser in registers
- *   phase 3  Huffman: bit lengths -> workgroup scan -> each lane ORs its codes
- *            into the strip's bit buffer in LDS at its own bit offset
- * The DC predictor of the strip's first MCU comes from recomputing the MCU
- * just before the strip (a one-MCU halo), so strips need no ordering.
+ *            AA&N "ifast") and the divide-with-rounding quantiser in
+ *            registers; the coefficients go to LDS in zigzag order
+ *   phase 3  Huffman, one wavefront per strip, one block at a time with a lane
+ *            per zigzag position: the run before a coefficient comes from a
+ *            ballot of "non-zero", code lengths are prefix-summed over the 64
+ *            lanes, and every lane ORs its code into a small LDS ring that is
+ *            flushed to the strip's slot as words complete
+ * The DC predictor of the group's first MCU comes from recomputing the MCU
+ * just before it (a one-MCU halo), so groups need no ordering.
  *
  * The three small kernels after it work on compressed bytes only: scan of
  * strip bit counts, bit-granular concatenation, 0xFF byte stuffing.
@@ -22,12 +27,21 @@
 
 #include "jpeg_device.h"
 #include "runtime.h"
+#include "wave_ops.h"
 
 #define JT JPEG_STRIP_THREADS
-#define JSLOTS (JPEG_STRIP_MCUS + 1)          /* slot 0 is the halo MCU */
+#define JG_MCUS (JPEG_STRIP_MCUS * JPEG_GROUP_STRIPS)
+#define JSLOTS (JG_MCUS + 1)                  /* slot 0 is the halo MCU */
 #define YT_STRIDE (JSLOTS * 16)               /* bytes per luma tile row */
 #define CT_STRIDE (JSLOTS * 8)
-#define JBITBUF_WORDS 5120                    /* 20 KiB of LDS for a strip's bits */
+#define JCOEF_STRIDE 33                       /* words per block in LDS: 64 int16 + 1 against bank conflicts */
+#define JRING_WORDS 128                       /* per wavefront; a block adds at most 52 words */
+
+#ifdef SPICE_WAVE_SIM
+#define JPEG_GLOBAL
+#else
+#define JPEG_GLOBAL __attribute__((address_space(1)))
+#endif
 
 /* zigzag position -> natural index */
 #define JZZ_LIST \
@@ -36,27 +50,44 @@
     52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63
 
 /* ---------------------------------------------------------------- pixels */
-/* r | g << 8 | b << 16 of source pixel (x, y); converters of mjpeg_encoder.c:236-259 */
-__device__ __forceinline__ uint32_t jpeg_fetch_rgb(const JpegDevJob &job, int x, int y)
+/* Source pixel (x, y) as stored, and its conversion to r | g << 8 | b << 16
+ * (converters of mjpeg_encoder.c:236-259).  FMT: 6 x1r5g5b5, 7 b,g,r bytes,
+ * 8 / 9 b,g,r,pad, JPEG_FMT_RGB24 r,g,b bytes.  The format is a template
+ * parameter so that a lane's loads can all be in flight before the first
+ * conversion waits for one. */
+template <int FMT>
+__device__ __forceinline__ uint32_t jpeg_fetch_raw(const JpegDevJob &job, int x, int y)
 {
-    const uint8_t *row = job.pixels + (int64_t)y * job.stride;
-    if (job.format == 8 || job.format == 9) {
-        const uint32_t p = ((const uint32_t *)row)[x];
-        return ((p >> 16) & 0xff) | (p & 0xff00) | ((p & 0xff) << 16);
-    } else if (job.format == 7) {
-        const uint8_t *p = row + x * 3;
-        return (uint32_t)p[2] | ((uint32_t)p[1] << 8) | ((uint32_t)p[0] << 16);
-    } else if (job.format == JPEG_FMT_RGB24) {
-        /* already r,g,b: convert_RGB24_to_RGB24, server/jpeg_encoder.c:160-163 */
-        const uint8_t *p = row + x * 3;
+    const JPEG_GLOBAL uint8_t *row = (const JPEG_GLOBAL uint8_t *)(uintptr_t)job.pixels + (int64_t)y * job.stride;
+    if (FMT == 8 || FMT == 9) {
+        return ((const JPEG_GLOBAL uint32_t *)row)[x];
+    } else if (FMT == 7 || FMT == JPEG_FMT_RGB24) {
+        const JPEG_GLOBAL uint8_t *p = row + x * 3;
         return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
     } else {
-        const uint32_t p = ((const uint16_t *)row)[x];
+        return ((const JPEG_GLOBAL uint16_t *)row)[x];
+    }
+}
+
+template <int FMT>
+__device__ __forceinline__ uint32_t jpeg_raw_to_rgb(uint32_t p)
+{
+    if (FMT == 8 || FMT == 9 || FMT == 7) {
+        return ((p >> 16) & 0xff) | (p & 0xff00) | ((p & 0xff) << 16);
+    } else if (FMT == JPEG_FMT_RGB24) {
+        return p; /* already r,g,b: convert_RGB24_to_RGB24, server/jpeg_encoder.c:160-163 */
+    } else {
         const uint32_t r = ((p >> 7) & 0xf8) | ((p >> 12) & 0x7);
         const uint32_t g = ((p >> 2) & 0xf8) | ((p >> 7) & 0x7);
         const uint32_t b = ((p << 3) & 0xf8) | ((p >> 2) & 0x7);
         return r | (g << 8) | (b << 16);
     }
+}
+
+template <int FMT>
+__device__ __forceinline__ uint32_t jpeg_fetch_rgb(const JpegDevJob &job, int x, int y)
+{
+    return jpeg_raw_to_rgb<FMT>(jpeg_fetch_raw<FMT>(job, x, y));
 }
 
 /* libjpeg jccolor.c, 16-bit fixed point */
@@ -182,114 +213,21 @@ __device__ __forceinline__ int jpeg_quant(int v, int d, float rcp)
 
 /* ---------------------------------------------------------------- Huffman */
 /* packed table entry: size << 16 | code */
-struct JpegBitWriter {
-    uint32_t *words;
-    uint32_t widx;
-    uint64_t acc;
-    int n;
-    bool first;
-};
-
-__device__ __forceinline__ void jpeg_bw_init(JpegBitWriter &w, uint32_t *words, uint32_t bitpos)
-{
-    w.words = words;
-    w.widx = bitpos >> 5;
-    w.n = (int)(bitpos & 31);
-    w.acc = 0;
-    w.first = true;
-}
-
-__device__ __forceinline__ void jpeg_bw_put(JpegBitWriter &w, uint32_t code, int size)
-{
-    w.acc = (w.acc << size) | (uint64_t)(code & ((1u << size) - 1));
-    w.n += size;
-    if (w.n >= 32) {
-        const uint32_t v = (uint32_t)(w.acc >> (w.n - 32));
-        if (w.first) {
-            atomicOr(&w.words[w.widx], v); /* shared with the previous block's tail */
-            w.first = false;
-        } else {
-            w.words[w.widx] = v;
-        }
-        w.widx++;
-        w.n -= 32;
-        w.acc &= (1ull << w.n) - 1;
-    }
-}
-
-__device__ __forceinline__ void jpeg_bw_finish(JpegBitWriter &w)
-{
-    if (w.n > 0) {
-        atomicOr(&w.words[w.widx], (uint32_t)(w.acc << (32 - w.n)));
-    }
-}
-
 __device__ __forceinline__ int jpeg_nbits(int a)
 {
     return 32 - __clz(a);
 }
 
-/* libjpeg jchuff.c encode_one_block.  EMIT=false only adds up the bits. */
-template <bool EMIT>
-__device__ __forceinline__ int jpeg_huff_block(const int (&c)[64], int diff, const uint32_t *dc_tab,
-                                               const uint32_t *ac_tab, JpegBitWriter &w)
+/* ORs the low `len` (1..32) bits of `code` into the bit stream at position
+ * `pos` (MSB first inside 32-bit words of a ring of JRING_WORDS words). */
+__device__ __forceinline__ void jpeg_ring_put(uint32_t *ring, uint32_t pos, uint32_t code, int len)
 {
-    constexpr int zz[64] = {JZZ_LIST};
-    int bits = 0;
-    {
-        int t = diff, t2 = diff;
-        if (t < 0) {
-            t = -t;
-            t2--;
-        }
-        const int nb = t ? jpeg_nbits(t) : 0;
-        const uint32_t e = dc_tab[nb];
-        bits += (int)(e >> 16) + nb;
-        if (EMIT) {
-            jpeg_bw_put(w, e & 0xffff, (int)(e >> 16));
-            if (nb) {
-                jpeg_bw_put(w, (uint32_t)t2, nb);
-            }
-        }
+    const uint32_t w0 = pos >> 5;
+    const uint64_t t = (uint64_t)code << (64 - (int)(pos & 31) - len);
+    atomicOr(&ring[w0 & (JRING_WORDS - 1)], (uint32_t)(t >> 32));
+    if ((uint32_t)t) {
+        atomicOr(&ring[(w0 + 1) & (JRING_WORDS - 1)], (uint32_t)t);
     }
-    int r = 0;
-#pragma unroll
-    for (int k = 1; k < 64; k++) {
-        int t = c[zz[k]];
-        if (t == 0) {
-            r++;
-        } else {
-            while (r > 15) {
-                const uint32_t z = ac_tab[0xf0];
-                bits += (int)(z >> 16);
-                if (EMIT) {
-                    jpeg_bw_put(w, z & 0xffff, (int)(z >> 16));
-                }
-                r -= 16;
-            }
-            int t2 = t;
-            if (t < 0) {
-                t = -t;
-                t2--;
-            }
-            const int nb = jpeg_nbits(t);
-            const uint32_t e = ac_tab[(r << 4) + nb];
-            bits += (int)(e >> 16) + nb;
-            if (EMIT) {
-                jpeg_bw_put(w, e & 0xffff, (int)(e >> 16));
-                jpeg_bw_put(w, (uint32_t)t2, nb);
-            }
-            r = 0;
-        }
-    }
-    if (r > 0) {
-        const uint32_t e = ac_tab[0];
-        bits += (int)(e >> 16);
-        if (EMIT) {
-            jpeg_bw_put(w, e & 0xffff, (int)(e >> 16));
-        }
-    }
-    return bits;
 }
 
 /* Exclusive scan of one int per lane over the workgroup; *total gets the sum. */
@@ -324,37 +262,48 @@ __device__ __forceinline__ int jpeg_block_scan(int v, int *wave_sums, int tid, i
 /* huff: [0..255] AC luma, [256..511] AC chroma, [512..527] DC luma, [528..543] DC chroma */
 #define JHUFF_WORDS 544
 
-template <bool IFAST>
-__device__ void jpeg_strip_body(const JpegDevJob &job, const uint32_t *huff_g, int strip)
+/* Phase 1 of the strip kernel for one pixel format: the group's pixels (and
+ * its halo MCU's) become luma and 2x2-averaged chroma samples in the LDS tiles. */
+template <int FMT>
+__device__ __forceinline__ void jpeg_load_tiles(const JpegDevJob &job, uint8_t *ytile, uint8_t *cbtile,
+                                                uint8_t *crtile, int tid, int ns, bool has_halo, int hx,
+                                                int hy, int mx0, int my)
 {
-    __shared__ __align__(16) uint8_t ytile[16 * YT_STRIDE];
-    __shared__ __align__(16) uint8_t cbtile[8 * CT_STRIDE];
-    __shared__ __align__(16) uint8_t crtile[8 * CT_STRIDE];
-    __shared__ int dcq[JSLOTS * 6];
-    __shared__ int lens[JT];
-    __shared__ int wave_sums[JT / 64];
-    __shared__ uint32_t huff[JHUFF_WORDS];
-    __shared__ uint32_t bitbuf[JBITBUF_WORDS];
-
-    const int tid = (int)threadIdx.x;
-    const int my = strip / job.strips_per_row;
-    const int mx0 = (strip % job.strips_per_row) * JPEG_STRIP_MCUS;
-    const int nm = min(JPEG_STRIP_MCUS, job.mcu_cols - mx0);
-    const bool has_halo = strip != 0;
-    const int ns = nm + 1;
-    /* the MCU coded just before this strip */
-    const int hlin = my * job.mcu_cols + mx0 - 1;
-    const int hy = has_halo ? hlin / job.mcu_cols : 0, hx = has_halo ? hlin % job.mcu_cols : 0;
     const int W = job.width, H = job.height;
     const int ch = (H + 1) >> 1; /* real downsampled rows */
-
-    for (int i = tid; i < JHUFF_WORDS; i += JT) {
-        huff[i] = huff_g[i];
-    }
-
-    /* ---- phase 1: 2x2 pixel quads -> 4 luma samples + 1 Cb + 1 Cr */
+    /* ---- phase 1: 2x2 pixel quads -> 4 luma samples + 1 Cb + 1 Cr.  All of a
+     * lane's pixels are requested before the first is used. */
     const int quads_x = ns * 8;
-    for (int item = tid; item < quads_x * 8; item += JT) {
+    constexpr int JQ_ITERS = (JSLOTS * 64 + JT - 1) / JT;
+    uint32_t px[JQ_ITERS][4];
+#pragma unroll
+    for (int it = 0; it < JQ_ITERS; it++) {
+        const int item = tid + it * JT;
+        px[it][0] = px[it][1] = px[it][2] = px[it][3] = 0;
+        if (item < quads_x * 8) {
+            const int qy = item / quads_x, qxs = item - qy * quads_x;
+            const int slot = qxs >> 3, qx = qxs & 7;
+            if (slot != 0 || has_halo) {
+                const int mcx = slot == 0 ? hx : mx0 + slot - 1;
+                const int mcy = slot == 0 ? hy : my;
+                const int x = mcx * 16 + qx * 2;
+                /* chroma: rows are replicated after downsampling (jcprepct.c), columns before (jcsample.c) */
+                const int cyc = min(mcy * 8 + qy, ch - 1);
+                const int r0 = min(2 * cyc, H - 1), r1 = min(2 * cyc + 1, H - 1);
+                const int c0 = min(x, W - 1), c1 = min(x + 1, W - 1);
+                px[it][0] = jpeg_fetch_raw<FMT>(job, c0, r0);
+                px[it][1] = jpeg_fetch_raw<FMT>(job, c1, r0);
+                px[it][2] = jpeg_fetch_raw<FMT>(job, c0, r1);
+                px[it][3] = jpeg_fetch_raw<FMT>(job, c1, r1);
+            }
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < JQ_ITERS; it++) {
+        const int item = tid + it * JT;
+        if (item >= quads_x * 8) {
+            continue;
+        }
         const int qy = item / quads_x, qxs = item - qy * quads_x;
         const int slot = qxs >> 3, qx = qxs & 7;
         if (slot == 0 && !has_halo) {
@@ -363,12 +312,9 @@ __device__ void jpeg_strip_body(const JpegDevJob &job, const uint32_t *huff_g, i
         const int mcx = slot == 0 ? hx : mx0 + slot - 1;
         const int mcy = slot == 0 ? hy : my;
         const int x = mcx * 16 + qx * 2, y = mcy * 16 + qy * 2;
-        /* chroma: rows are replicated after downsampling (jcprepct.c), columns before (jcsample.c) */
-        const int cyc = min(mcy * 8 + qy, ch - 1);
-        const int r0 = min(2 * cyc, H - 1), r1 = min(2 * cyc + 1, H - 1);
         const int c0 = min(x, W - 1), c1 = min(x + 1, W - 1);
-        const uint32_t p00 = jpeg_fetch_rgb(job, c0, r0), p01 = jpeg_fetch_rgb(job, c1, r0);
-        const uint32_t p10 = jpeg_fetch_rgb(job, c0, r1), p11 = jpeg_fetch_rgb(job, c1, r1);
+        const uint32_t p00 = jpeg_raw_to_rgb<FMT>(px[it][0]), p01 = jpeg_raw_to_rgb<FMT>(px[it][1]);
+        const uint32_t p10 = jpeg_raw_to_rgb<FMT>(px[it][2]), p11 = jpeg_raw_to_rgb<FMT>(px[it][3]);
         const int bias = (qx & 1) ? 2 : 1; /* chroma column parity within the MCU == global parity */
         const int cb = (jpeg_cb(p00) + jpeg_cb(p01) + jpeg_cb(p10) + jpeg_cb(p11) + bias) >> 2;
         const int cr = (jpeg_cr(p00) + jpeg_cr(p01) + jpeg_cr(p10) + jpeg_cr(p11) + bias) >> 2;
@@ -378,16 +324,70 @@ __device__ void jpeg_strip_body(const JpegDevJob &job, const uint32_t *huff_g, i
         uint32_t q00 = p00, q01 = p01, q10 = p10, q11 = p11;
         if (y + 1 >= H) {
             const int y0 = min(y, H - 1), y1 = min(y + 1, H - 1);
-            q00 = jpeg_fetch_rgb(job, c0, y0);
-            q01 = jpeg_fetch_rgb(job, c1, y0);
-            q10 = jpeg_fetch_rgb(job, c0, y1);
-            q11 = jpeg_fetch_rgb(job, c1, y1);
+            q00 = jpeg_fetch_rgb<FMT>(job, c0, y0);
+            q01 = jpeg_fetch_rgb<FMT>(job, c1, y0);
+            q10 = jpeg_fetch_rgb<FMT>(job, c0, y1);
+            q11 = jpeg_fetch_rgb<FMT>(job, c1, y1);
         }
         uint8_t *yp = &ytile[(qy * 2) * YT_STRIDE + slot * 16 + qx * 2];
         yp[0] = (uint8_t)jpeg_y(q00);
         yp[1] = (uint8_t)jpeg_y(q01);
         yp[YT_STRIDE] = (uint8_t)jpeg_y(q10);
         yp[YT_STRIDE + 1] = (uint8_t)jpeg_y(q11);
+    }
+}
+
+template <bool IFAST>
+__device__ void jpeg_strip_body(const JpegDevJob &job, const uint32_t *huff_g, int group)
+{
+    __shared__ __align__(16) uint8_t ytile[16 * YT_STRIDE];
+    __shared__ __align__(16) uint8_t cbtile[8 * CT_STRIDE];
+    __shared__ __align__(16) uint8_t crtile[8 * CT_STRIDE];
+    __shared__ int dcq[JSLOTS * 6];
+    __shared__ uint32_t huff[JHUFF_WORDS];
+    __shared__ int divs[128];                 /* divisors, luma then chroma */
+    __shared__ float rcps[128];
+    __shared__ uint32_t coef[JG_MCUS * 6 * JCOEF_STRIDE];
+    __shared__ uint32_t rings[(JT / 64) * JRING_WORDS];
+
+    const int tid = (int)threadIdx.x;
+    const int groups_per_row = (job.strips_per_row + JPEG_GROUP_STRIPS - 1) / JPEG_GROUP_STRIPS;
+    const int my = group / groups_per_row;
+    const int first_strip = (group % groups_per_row) * JPEG_GROUP_STRIPS;
+    const int mx0 = first_strip * JPEG_STRIP_MCUS;
+    const int nm = min(JG_MCUS, job.mcu_cols - mx0);
+    const bool has_halo = group != 0;
+    const int ns = nm + 1;
+    /* the MCU coded just before this strip */
+    const int hlin = my * job.mcu_cols + mx0 - 1;
+    const int hy = has_halo ? hlin / job.mcu_cols : 0, hx = has_halo ? hlin % job.mcu_cols : 0;
+
+    for (int i = tid; i < JHUFF_WORDS; i += JT) {
+        huff[i] = huff_g[i];
+    }
+    if (tid < 128) {
+        divs[tid] = tid < 64 ? job.div_y[tid] : job.div_c[tid - 64];
+        rcps[tid] = tid < 64 ? job.rcp_y[tid] : job.rcp_c[tid - 64];
+    }
+    for (int i = tid; i < (JT / 64) * JRING_WORDS; i += JT) {
+        rings[i] = 0;
+    }
+
+    /* ---- phase 1 */
+    switch (job.format) {
+    case 8:
+    case 9:
+        jpeg_load_tiles<8>(job, ytile, cbtile, crtile, tid, ns, has_halo, hx, hy, mx0, my);
+        break;
+    case 7:
+        jpeg_load_tiles<7>(job, ytile, cbtile, crtile, tid, ns, has_halo, hx, hy, mx0, my);
+        break;
+    case JPEG_FMT_RGB24:
+        jpeg_load_tiles<JPEG_FMT_RGB24>(job, ytile, cbtile, crtile, tid, ns, has_halo, hx, hy, mx0, my);
+        break;
+    default:
+        jpeg_load_tiles<6>(job, ytile, cbtile, crtile, tid, ns, has_halo, hx, hy, mx0, my);
+        break;
     }
     __syncthreads();
 
@@ -444,8 +444,8 @@ __device__ void jpeg_strip_body(const JpegDevJob &job, const uint32_t *huff_g, i
     }
     if (have && real) {
         jpeg_fdct<IFAST>(c);
-        const int *dv = bidx < 4 ? job.div_y : job.div_c;
-        const float *rc = bidx < 4 ? job.rcp_y : job.rcp_c;
+        const int *dv = divs + (bidx < 4 ? 0 : 64);
+        const float *rc = rcps + (bidx < 4 ? 0 : 64);
 #pragma unroll
         for (int i = 0; i < 64; i++) {
             c[i] = jpeg_quant(c[i], dv[i], rc[i]);
@@ -455,6 +455,16 @@ __device__ void jpeg_strip_body(const JpegDevJob &job, const uint32_t *huff_g, i
 #pragma unroll
         for (int i = 0; i < 64; i++) {
             c[i] = 0;
+        }
+    }
+    if (have && slot > 0) {
+        /* zigzag order, two coefficients per word; a dummy block is all zeros
+         * (its DC comes out of dcq below) */
+        constexpr int zz[64] = {JZZ_LIST};
+        uint32_t *dst = coef + ((slot - 1) * 6 + bidx) * JCOEF_STRIDE;
+#pragma unroll
+        for (int j = 0; j < 32; j++) {
+            dst[j] = ((uint32_t)c[zz[2 * j]] & 0xffffu) | ((uint32_t)c[zz[2 * j + 1]] << 16);
         }
     }
     __syncthreads();
@@ -470,68 +480,90 @@ __device__ void jpeg_strip_body(const JpegDevJob &job, const uint32_t *huff_g, i
     }
     __syncthreads();
 
-    /* ---- phase 3: Huffman */
-    const bool coded = have && slot > 0;
-    int diff = 0;
-    if (coded) {
-        const int dc = dcq[slot * 6 + bidx];
-        int pred;
-        if (bidx == 0) {
-            pred = (slot == 1 && !has_halo) ? 0 : dcq[(slot - 1) * 6 + 3];
-        } else if (bidx < 4) {
-            pred = dcq[slot * 6 + bidx - 1];
-        } else {
-            pred = (slot == 1 && !has_halo) ? 0 : dcq[(slot - 1) * 6 + bidx];
-        }
-        diff = dc - pred;
-        if (!real) {
-            c[0] = dc; /* not used by the coder, kept for clarity */
-        }
-    }
-    const uint32_t *ac_tab = huff + (bidx < 4 ? 0 : 256);
-    const uint32_t *dc_tab = huff + (bidx < 4 ? 512 : 528);
-    JpegBitWriter bw;
-    bw.words = nullptr;
-    int mybits = 0;
-    if (coded) {
-        mybits = jpeg_huff_block<false>(c, diff, dc_tab, ac_tab, bw);
-        lens[(slot - 1) * 6 + bidx] = mybits;
-    }
-    for (int i = tid; i < JBITBUF_WORDS; i += JT) {
-        bitbuf[i] = 0;
-    }
-    __syncthreads();
-    int total = 0;
-    const int mine = tid < nm * 6 ? lens[tid] : 0;
-    const int excl = jpeg_block_scan(mine, wave_sums, tid, &total);
-    if (tid < nm * 6) {
-        lens[tid] = excl; /* now the bit offset of block tid (MCU order) */
-    }
-    __syncthreads();
+    /* ---- phase 3: Huffman, one wavefront per strip */
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63; /* scalar: the loop below is uniform */
+    const int strip_in_row = first_strip + wave;
+    if (strip_in_row < job.strips_per_row) {
+        const int strip = my * job.strips_per_row + strip_in_row;
+        const int m0 = wave * JPEG_STRIP_MCUS, m1 = min(m0 + JPEG_STRIP_MCUS, nm);
+        uint32_t *ring = rings + wave * JRING_WORDS;
+        JPEG_GLOBAL uint32_t *out_words =
+            (JPEG_GLOBAL uint32_t *)(uintptr_t)(job.strip_buf + (size_t)strip * job.strip_stride);
+        const uint16_t *coef16 = (const uint16_t *)coef;
+        uint32_t bits = 0, flushed = 0; /* stream bits so far; words already in the slot */
 
-    uint32_t *slot_words = (uint32_t *)(job.strip_buf + (size_t)strip * job.strip_stride);
-    const int nwords = (total + 31) >> 5;
-    const bool in_lds = nwords <= JBITBUF_WORDS;
-    uint32_t *words = in_lds ? bitbuf : slot_words;
-    if (!in_lds) {
-        for (int i = tid; i < nwords; i += JT) {
-            slot_words[i] = 0;
+        const uint32_t zrl = huff[0xf0], zrl_c = huff[256 + 0xf0];
+        int vnext = m0 < m1 ? (int)(int16_t)coef16[m0 * 6 * (JCOEF_STRIDE * 2) + lane] : 0;
+        for (int b = m0 * 6; b < m1 * 6; b++) {
+            const int bslot = b / 6 + 1, bi = b - (bslot - 1) * 6;
+            int v = vnext;
+            if (b + 1 < m1 * 6) {
+                vnext = (int)(int16_t)coef16[(b + 1) * (JCOEF_STRIDE * 2) + lane];
+            }
+            /* DC difference, jchuff.c encode_one_block; every lane reads the same words */
+            int pred;
+            if (bi == 0) {
+                pred = (bslot == 1 && !has_halo) ? 0 : dcq[(bslot - 1) * 6 + 3];
+            } else if (bi < 4) {
+                pred = dcq[bslot * 6 + bi - 1];
+            } else {
+                pred = (bslot == 1 && !has_halo) ? 0 : dcq[(bslot - 1) * 6 + bi];
+            }
+            v = lane == 0 ? dcq[bslot * 6 + bi] - pred : v;
+            const int ac_off = bi < 4 ? 0 : 256, dc_off = bi < 4 ? 512 : 528;
+
+            /* one code per lane: DC (lane 0), a non-zero AC coefficient with the
+             * zero run before it, or the end-of-block code when the block ends
+             * in zeros (lane 63) */
+            const uint64_t nz = __ballot(v != 0) & ~1ull;
+            const int t = v < 0 ? -v : v, t2 = v + (v >> 31);
+            const int nb = 32 - __clz(t);
+            const uint32_t vbits = (uint32_t)t2 & ((1u << nb) - 1);
+            const uint64_t before = nz & ((1ull << lane) - 1);
+            const int run = lane - 1 - (before ? 63 - __clzll((long long)before) : 0);
+            const bool ac = v != 0 && lane != 0;
+            const int idx = lane == 0 ? dc_off + nb : ac_off + (ac ? ((run & 15) << 4) + nb : 0);
+            const uint32_t e = huff[idx];
+            const int es = (int)(e >> 16);
+            const uint32_t code = ((e & 0xffff) << nb) | vbits;
+            int len = (ac || lane == 0 || lane == 63) ? es + nb : 0;
+            /* runs of 16 zeros and more take ZRL codes first; rare */
+            const int nzrl = ac ? run >> 4 : 0;
+            const uint32_t z = bi < 4 ? zrl : zrl_c;
+            const bool any_zrl = __ballot(nzrl != 0) != 0;
+            if (any_zrl) {
+                len += nzrl * (int)(z >> 16);
+            }
+            const uint32_t inc = wave_scan_inclusive((uint32_t)len, lane);
+            const uint32_t total = wave_broadcast(inc, 63);
+            if (len) {
+                uint32_t pos = bits + inc - (uint32_t)len;
+                if (any_zrl) {
+                    for (int i = 0; i < nzrl; i++) {
+                        jpeg_ring_put(ring, pos, z & 0xffff, (int)(z >> 16));
+                        pos += z >> 16;
+                    }
+                }
+                jpeg_ring_put(ring, pos, code, es + nb);
+            }
+            bits += total;
+            __builtin_amdgcn_wave_barrier();
+            /* complete words leave the ring: the stream is MSB first, memory wants bytes in order */
+            const uint32_t done = bits >> 5;
+            if (done - flushed >= 32 || b + 1 == m1 * 6) {
+                const uint32_t upto = b + 1 == m1 * 6 ? (bits + 31) >> 5 : done;
+                for (uint32_t i = flushed + (uint32_t)lane; i < upto; i += 64) {
+                    const uint32_t w = ring[i & (JRING_WORDS - 1)];
+                    ring[i & (JRING_WORDS - 1)] = 0;
+                    out_words[i] = (w >> 24) | ((w >> 8) & 0xff00) | ((w << 8) & 0xff0000) | (w << 24);
+                }
+                flushed = upto;
+                __builtin_amdgcn_wave_barrier();
+            }
         }
-        __syncthreads();
-    }
-    if (coded) {
-        jpeg_bw_init(bw, words, (uint32_t)lens[(slot - 1) * 6 + bidx]);
-        jpeg_huff_block<true>(c, diff, dc_tab, ac_tab, bw);
-        jpeg_bw_finish(bw);
-    }
-    __syncthreads();
-    /* words hold the stream MSB first; memory order wants the bytes swapped */
-    for (int i = tid; i < nwords; i += JT) {
-        const uint32_t v = words[i];
-        slot_words[i] = (v >> 24) | ((v >> 8) & 0xff00) | ((v << 8) & 0xff0000) | (v << 24);
-    }
-    if (tid == 0) {
-        job.strip_bits[strip] = (uint32_t)total;
+        if (lane == 0) {
+            job.strip_bits[strip] = bits;
+        }
     }
 }
 
@@ -540,11 +572,12 @@ __global__ void __launch_bounds__(JT)
 jpeg_strip_kernel(const JpegDevJob *jobs, const uint32_t *huff)
 {
     const JpegDevJob &job = jobs[blockIdx.y];
-    const int strip = (int)blockIdx.x;
-    if (strip >= job.nstrips || (job.dct != 0) != IFAST) {
+    const int group = (int)blockIdx.x;
+    const int groups_per_row = (job.strips_per_row + JPEG_GROUP_STRIPS - 1) / JPEG_GROUP_STRIPS;
+    if (group >= groups_per_row * job.mcu_rows || (job.dct != 0) != IFAST) {
         return;
     }
-    jpeg_strip_body<IFAST>(job, huff, strip);
+    jpeg_strip_body<IFAST>(job, huff, group);
 }
 
 /* Exclusive scan of strip_bits into strip_bitoff (64-bit), one workgroup per job. */
@@ -727,10 +760,10 @@ jpeg_finish_kernel(const JpegDevJob *jobs)
     }
 }
 
-void jpeg_launch(const JpegDevJob *jobs, int njobs, int max_strips, bool any_islow, bool any_ifast,
+void jpeg_launch(const JpegDevJob *jobs, int njobs, int max_groups, bool any_islow, bool any_ifast,
                  const uint32_t *huff, hipStream_t stream)
 {
-    const dim3 grid((unsigned)max_strips, (unsigned)njobs);
+    const dim3 grid((unsigned)max_groups, (unsigned)njobs);
     int t;
     if (any_islow) {
         t = spicegpu::timing_begin("jpeg_strip_kernel_islow", stream);
