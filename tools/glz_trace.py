@@ -1,5 +1,5 @@
 import sys, ctypes, numpy as np
-sys.path.insert(0,'.')
+import os; ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from oracle import oracle as O
 from spice_amd import frames
 W,H=1920,1080

@@ -28,8 +28,3 @@ for _ in range(5):
     except Exception as e: pass
 dt=(time.time()-t0)/5
 print(lib, 'ms/batch %.3f'%(dt*1e3), {k:round(v[1]/max(1,v[0]),3) for k,v in gpu.kernel_times().items()})
-if lib and 'jk_p' in lib:
-    prof=(ctypes.c_ulonglong*16)()
-    gpu.L.spice_gpu_debug_prof(prof,0)
-    v=list(prof); n=max(1,v[7])
-    print('per WG us:', {k: round(v[i]/100.0/n,2) for i,k in enumerate(['setup','fetch','colour','tile2reg','dct_quant','coefstore+dc','huffman'])}, 'wgs sampled', n)
