@@ -8,21 +8,26 @@
  * byte-identical -- but splits the work on a window of GLZ_WIN consecutive
  * positions into three phases:
  *
- *   scan (all four wavefronts, one position per lane): run test, 3-pixel hash,
- *      hash-table probe with reference validation (REF_SEG_IS_VALID,
- *      glz_encoder_dictionary_protected.h:176-184) and do_match's rules
- *      (glz_encode_tmpl.c:147-262) for the slot's content as it was when the
- *      window was entered, and the same for the two nearest earlier window
- *      positions with the same hash (found through an LDS bitmap keyed by the
- *      hash's low bits).  Every candidate is compared over its first GLZ_K
- *      pixels and the accept / reject decision is taken here;
+ *   scan (all four wavefronts, one position per lane): run test and run
+ *      length, 3-pixel hash, hash-table probe with reference validation
+ *      (REF_SEG_IS_VALID, glz_encoder_dictionary_protected.h:176-184) and
+ *      do_match's rules (glz_encode_tmpl.c:147-262) for the slot's content as
+ *      it was when the window was entered, and the same for the two nearest
+ *      earlier window positions with the same hash (found through an LDS
+ *      bitmap keyed by the hash's low bits).  Every candidate is compared over
+ *      its first GLZ_K pixels and the accept / reject decision is taken here;
  *   resolve (wavefront 0): visits the real stops in order.  The table slot a
  *      stop sees is the most recent store to it: the nearest earlier window
  *      position with that hash that really was a store (a stop or one of the
- *      two positions stored after a match), else what the scan read.  Per stop
- *      this is a handful of register reads; only candidates that outgrow
- *      GLZ_K pixels, or whose two nearest predecessors were both skipped, fall
- *      back to wave-wide compares;
+ *      two positions stored after a match), else what the scan read.  The walk
+ *      goes a quarter (64 positions) at a time with the quarter's marks in
+ *      64-bit scalar registers; on entering a quarter each lane settles the
+ *      candidates that lie in finished quarters, so that an ordinary stop is
+ *      one v_readlane plus scalar bit tests (glz_fast_stops, written in GCN
+ *      assembly because one wavefront issues an instruction every ~5 cycles
+ *      and each one counts).  Only candidates that outgrow GLZ_K pixels, runs
+ *      that leave the window and slots whose two nearest predecessors were
+ *      both skipped take glz_resolve_general with wave-wide compares;
  *   emit (all four wavefronts): sizes of the window's literals and matches are
  *      prefix-summed and every lane writes its own token; the window's table
  *      stores are issued here too, one per slot (the last store wins).
