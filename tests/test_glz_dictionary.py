@@ -1,0 +1,107 @@
+"""The GLZ dictionary's life cycle through the drop-in API, against the oracle:
+reset, migration restore (glz_enc_dictionary_get_restore_data / _restore,
+server/glz_encoder_dictionary.c:96-160), and two encoders of one client sharing
+a dictionary (server/red_worker.c:9677-9754; each encoder holds back the window
+head while it encodes, glz_encoder_dictionary.c:550-633)."""
+import numpy as np
+import pytest
+
+from spice_amd import binding as B
+
+from helpers import assert_same_stream, pixels_for, small_desktop, split_rows
+
+T32 = B.LZ_IMAGE_TYPE_RGB32
+
+
+def images(n, seed0, w=120, h=48):
+    rng = np.random.default_rng(seed0)
+    return [pixels_for(T32, small_desktop(w, h, seed0 + k // 2), rng) for k in range(n)], w, h
+
+
+def run_reset(dev, oracle):
+    imgs, w, h = images(6, 40)
+    od = oracle.GlzDict(20000, 1)
+    gd = B.GlzDictionary(dev, 20000, 1)
+    ge = B.GlzEncoder(dev, gd, 0)
+    try:
+        for k, px in enumerate(imgs):
+            if k == 3:
+                od.reset()
+                gd.reset()
+            so, _ = od.encode(T32, w, h, w * 4, [px], usr_tag=k + 1)
+            sg, _ = ge.encode(T32, w, h, w * 4, [px], usr_context=k + 1)
+            assert_same_stream(so, sg, "image %d around a reset" % k)
+        # the reset freed every image that was still in the window
+        assert od.pop_freed() == gd.usr.freed_images
+    finally:
+        ge.close()
+        gd.close()
+        od.close()
+
+
+def run_restore(dev, oracle):
+    imgs, w, h = images(6, 60)
+    od = oracle.GlzDict(30000, 2)
+    gd = B.GlzDictionary(dev, 30000, 2)
+    ge = B.GlzEncoder(dev, gd, 0)
+    for k, px in enumerate(imgs[:3]):
+        so, _ = od.encode(T32, w, h, w * 4, [px], usr_tag=k + 1)
+        sg, _ = ge.encode(T32, w, h, w * 4, [px], usr_context=k + 1)
+        assert_same_stream(so, sg, "image %d before migration" % k)
+    want = od.restore_data()
+    got = gd.get_restore_data()
+    assert (got.size, got.max_encoders, got.last_image_id) == want
+    ge.close()
+    gd.close()
+    od.close()
+    # the target host starts from the restore data: empty window, image ids go on
+    od = oracle.GlzDict(want[0], want[1], restore_last_id=want[2])
+    gd = B.GlzDictionary(dev, 0, 0, restore=got)
+    ge = B.GlzEncoder(dev, gd, 1)
+    try:
+        assert gd.get_size() == want[0]
+        for k, px in enumerate(imgs[3:]):
+            so, _ = od.encode(T32, w, h, w * 4, [px], encoder_id=1, usr_tag=10 + k)
+            sg, _ = ge.encode(T32, w, h, w * 4, [px], usr_context=10 + k)
+            assert_same_stream(so, sg, "image %d after migration" % k)
+    finally:
+        ge.close()
+        gd.close()
+        od.close()
+
+
+def run_two_encoders(dev, oracle):
+    """Two display channels of one client take turns on one dictionary; the
+    window is small, so images of both are evicted along the way."""
+    imgs, w, h = images(10, 80)
+    od = oracle.GlzDict(25000, 2)
+    gd = B.GlzDictionary(dev, 25000, 2)
+    enc = [B.GlzEncoder(dev, gd, 0), B.GlzEncoder(dev, gd, 1)]
+    try:
+        for k, px in enumerate(imgs):
+            who = (k // 2) % 2
+            chunks = split_rows(px, 1 + k % 2)
+            so, _ = od.encode(T32, w, h, w * 4, chunks, encoder_id=who, usr_tag=k + 1)
+            sg, _ = enc[who].encode(T32, w, h, w * 4, chunks, usr_context=k + 1)
+            assert_same_stream(so, sg, "image %d by encoder %d" % (k, who))
+            assert od.pop_freed() == gd.usr.freed_images
+            gd.usr.freed_images.clear()
+    finally:
+        for e in enc:
+            e.close()
+        gd.close()
+        od.close()
+
+
+CASES = [run_reset, run_restore, run_two_encoders]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda f: f.__name__)
+def test_sim_dictionary(sim, oracle, case):
+    case(sim, oracle)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES, ids=lambda f: f.__name__)
+def test_gpu_dictionary(gpu, oracle, case):
+    case(gpu, oracle)
