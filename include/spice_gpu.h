@@ -162,10 +162,10 @@ typedef struct MJpegEncoderStats {
     double avg_quality;
 } MJpegEncoderStats;
 
-/* server/mjpeg_encoder.h:52-54.  Only bit_rate_control == 0 is accepted in
- * this build (static quality 70, server/mjpeg_encoder.c:33,213); rate control
- * is host policy layered on top of the codec and is not part of this path.
- * Returns NULL, with spice_gpu_last_error set, when asked for it. */
+/* server/mjpeg_encoder.h:52-54.  With bit_rate_control != 0, cbs must carry
+ * get_roundtrip_ms and get_source_fps (server/mjpeg_encoder.c:192); the stream
+ * then starts probing from quality 50 at 5 fps.  Without it the quality is a
+ * fixed 70 (server/mjpeg_encoder.c:33,213). */
 MJpegEncoder *mjpeg_encoder_new(int bit_rate_control, uint64_t starting_bit_rate,
                                 MJpegEncoderRateControlCbs *cbs, void *opaque);
 void mjpeg_encoder_destroy(MJpegEncoder *encoder);
@@ -179,9 +179,60 @@ int mjpeg_encoder_start_frame(MJpegEncoder *encoder, int format, int width, int 
 int mjpeg_encoder_encode_scanline(MJpegEncoder *encoder, uint8_t *src_pixels, size_t image_width);
 /* server/mjpeg_encoder.h:75.  Runs the frame on the GPU; returns the JFIF size. */
 size_t mjpeg_encoder_end_frame(MJpegEncoder *encoder);
+/* server/mjpeg_encoder.h:94-100: a periodic report from the client about the
+ * frames it received (end_frame_delay = end_frame_mm_time - client mm_time;
+ * audio_delay = UINT32_MAX when no audio plays). */
+void mjpeg_encoder_client_stream_report(MJpegEncoder *encoder, uint32_t num_frames,
+                                        uint32_t num_drops, uint32_t start_frame_mm_time,
+                                        uint32_t end_frame_mm_time, int32_t end_frame_delay,
+                                        uint32_t audio_delay);
+/* server/mjpeg_encoder.h:109: a frame was dropped because the pipe was congested */
+void mjpeg_encoder_notify_server_frame_drop(MJpegEncoder *encoder);
 /* server/mjpeg_encoder.h:111-112 */
 uint64_t mjpeg_encoder_get_bit_rate(MJpegEncoder *encoder);
 void mjpeg_encoder_get_stats(MJpegEncoder *encoder, MJpegEncoderStats *stats);
+
+/* Inspection of the rate controller, named after the fields of
+ * MJpegEncoderRateControl and its members (server/mjpeg_encoder.c:82-153).
+ * No counterpart in the reference, whose state is private to the .c file. */
+typedef struct SpiceGpuMjpegRateState {
+    int32_t during_quality_eval, eval_type, eval_reason;
+    int32_t min_quality_id, min_quality_fps, max_quality_id, max_quality_fps;
+    int32_t max_sampled_fps, max_sampled_fps_quality_id;
+    int32_t quality_id;
+    uint32_t fps;
+    uint32_t num_recent_enc_frames;
+    uint64_t encoded_size_by_quality[7];
+    double adjusted_fps;
+    uint64_t adjusted_fps_start_time, adjusted_fps_num_frames;
+    uint64_t byte_rate, base_enc_size, last_enc_size, sum_recent_enc_size;
+    uint64_t warmup_start_time;
+    uint64_t change_start_time, last_frame_time, sum_enc_size;
+    uint32_t change_start_mm_time, num_enc_frames;
+    int32_t was_upgraded, max_video_latency;
+    uint32_t max_audio_latency;
+    uint32_t num_frames_encoded, num_frames_dropped;
+    uint32_t playback_delay_updates, playback_delay_last; /* update_client_playback_delay calls */
+    uint32_t reserved;
+} SpiceGpuMjpegRateState;
+void spice_gpu_mjpeg_rate_state(MJpegEncoder *encoder, SpiceGpuMjpegRateState *out);
+/* Replace CLOCK_MONOTONIC (server/mjpeg_encoder.c:204,742,934) by now_ns(opaque);
+ * NULL restores it.  A stream still in its 3 s warm-up restarts the warm-up at
+ * the new clock's present.  For replaying recorded sessions and for tests. */
+void spice_gpu_mjpeg_set_clock(MJpegEncoder *encoder, uint64_t (*now_ns)(void *opaque), void *opaque);
+/* A rate controller with no codec behind it: mjpeg_encoder_start_frame on it
+ * always fails; frames are fed by size with spice_gpu_mjpeg_rate_feed, which
+ * does what start_frame (returns its DROP / ENCODE_START) and, when the frame
+ * is admitted, end_frame do to the controller.  size_by_quality_id[k] is the
+ * size the frame would have at quality 20 + 10k; the entry of the quality the
+ * controller picks is used, and 0 there stands for a frame whose scanlines
+ * failed (server/mjpeg_encoder.c:848-851).  Needs no GPU.  *quality receives
+ * the JPEG quality the frame is coded with. */
+MJpegEncoder *spice_gpu_mjpeg_rate_only_new(uint64_t starting_bit_rate,
+                                            MJpegEncoderRateControlCbs *cbs, void *opaque,
+                                            uint64_t (*now_ns)(void *opaque), void *clock_opaque);
+int spice_gpu_mjpeg_rate_feed(MJpegEncoder *encoder, uint32_t frame_mm_time,
+                              const uint64_t *size_by_quality_id, int *quality);
 
 /* ======================================================================
  * Section 1c -- still JPEG, drop-in for server/jpeg_encoder.h:35-60

@@ -25,7 +25,8 @@ def build(force=False):
     """Compiles liboracle.so (and _ref/libjpegref.so where libjpeg headers exist)."""
     so = os.path.join(HERE, "liboracle.so")
     srcs = ["glz_oracle.c", "glz_oracle.h", "glz_oracle_parse.inc", "jpeg_oracle.c",
-            "jpeg_oracle.h", "ref_jpeg_driver.c", "Makefile"]
+            "jpeg_oracle.h", "gradual_oracle.c", "mjpeg_rate_oracle.c", "ref_jpeg_driver.c",
+            "Makefile"]
     newest = max(os.path.getmtime(os.path.join(HERE, s)) for s in srcs)
     if force or not os.path.exists(so) or os.path.getmtime(so) < newest:
         subprocess.check_call(["make", "-s", "-C", HERE, "all"])
@@ -77,6 +78,22 @@ def lib():
         L.grado_choose.restype = C.c_int
         L.grado_choose.argtypes = [C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.c_uint32, C.c_int]
+        L.mjro_new.restype = C.c_void_p
+        L.mjro_new.argtypes = [C.c_uint64, C.c_uint64, C.c_int]
+        L.mjro_free.argtypes = [C.c_void_p]
+        L.mjro_env.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32]
+        L.mjro_feed.restype = C.c_int
+        L.mjro_feed.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
+        L.mjro_client_report.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                         C.c_int32, C.c_uint32]
+        L.mjro_server_drop.argtypes = [C.c_void_p]
+        L.mjro_state.argtypes = [C.c_void_p, C.c_void_p]
+        L.mjro_asserted.restype = C.c_int
+        L.mjro_asserted.argtypes = [C.c_void_p]
+        L.mjro_bit_rate.restype = C.c_uint64
+        L.mjro_bit_rate.argtypes = [C.c_void_p]
+        L.mjro_avg_quality.restype = C.c_double
+        L.mjro_avg_quality.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 
@@ -251,3 +268,74 @@ def choose_codec(comp, fmt, x, y, stride, unstable, can_lossy, enable_jpeg, grad
                  glz_dict_size, glz_frozen):
     return lib().grado_choose(comp, fmt, x, y, stride, int(unstable), int(can_lossy), int(enable_jpeg),
                               graduality_level, glz_dict_size, int(glz_frozen))
+
+
+class MjpegRateState(C.Structure):
+    """MJpegEncoderRateControl's fields (server/mjpeg_encoder.c:82-153), flattened."""
+    _fields_ = [(n, C.c_int32) for n in (
+        "during_quality_eval", "eval_type", "eval_reason", "min_quality_id", "min_quality_fps",
+        "max_quality_id", "max_quality_fps", "max_sampled_fps", "max_sampled_fps_quality_id",
+        "quality_id")] + [
+        ("fps", C.c_uint32), ("num_recent_enc_frames", C.c_uint32),
+        ("encoded_size_by_quality", C.c_uint64 * 7), ("adjusted_fps", C.c_double),
+        ("adjusted_fps_start_time", C.c_uint64), ("adjusted_fps_num_frames", C.c_uint64),
+        ("byte_rate", C.c_uint64), ("base_enc_size", C.c_uint64), ("last_enc_size", C.c_uint64),
+        ("sum_recent_enc_size", C.c_uint64), ("warmup_start_time", C.c_uint64),
+        ("change_start_time", C.c_uint64), ("last_frame_time", C.c_uint64),
+        ("sum_enc_size", C.c_uint64), ("change_start_mm_time", C.c_uint32),
+        ("num_enc_frames", C.c_uint32), ("was_upgraded", C.c_int32),
+        ("max_video_latency", C.c_int32), ("max_audio_latency", C.c_uint32),
+        ("num_frames_encoded", C.c_uint32), ("num_frames_dropped", C.c_uint32),
+        ("playback_delay_updates", C.c_uint32), ("playback_delay_last", C.c_uint32),
+        ("reserved", C.c_uint32)]
+
+    def as_dict(self):
+        d = {}
+        for name, _ in self._fields_:
+            v = getattr(self, name)
+            d[name] = list(v) if name == "encoded_size_by_quality" else v
+        return d
+
+
+class MjpegRate:
+    """The reference's rate controller with clock and callbacks as inputs
+    (server/mjpeg_encoder.c:362-727, 886-1258)."""
+
+    def __init__(self, starting_bit_rate, now_ns, has_delay_cb=True):
+        self.L = lib()
+        self.h = self.L.mjro_new(starting_bit_rate, now_ns, 1 if has_delay_cb else 0)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.mjro_free(self.h)
+            self.h = None
+
+    def env(self, now_ns, roundtrip_ms, source_fps):
+        self.L.mjro_env(self.h, now_ns, roundtrip_ms, source_fps)
+
+    def feed(self, mm_time, size_by_quality_id):
+        """-> (verdict, quality): verdict 0 drop, 1 coded, -1 the reference would have aborted.
+        size_by_quality_id: the frame's size at each of the 7 qualities (0 = scanline failure)."""
+        q = C.c_int(0)
+        r = self.L.mjro_feed(self.h, mm_time, (C.c_uint64 * 7)(*size_by_quality_id), C.byref(q))
+        return r, q.value
+
+    def client_report(self, num_frames, num_drops, start_mm, end_mm, end_delay, audio_delay):
+        self.L.mjro_client_report(self.h, num_frames, num_drops, start_mm, end_mm, end_delay, audio_delay)
+
+    def server_drop(self):
+        self.L.mjro_server_drop(self.h)
+
+    def state(self):
+        st = MjpegRateState()
+        self.L.mjro_state(self.h, C.byref(st))
+        return st.as_dict()
+
+    def asserted(self):
+        return bool(self.L.mjro_asserted(self.h))
+
+    def bit_rate(self):
+        return self.L.mjro_bit_rate(self.h)
+
+    def avg_quality(self):
+        return self.L.mjro_avg_quality(self.h)

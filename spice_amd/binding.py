@@ -94,6 +94,59 @@ class MJpegEncoderStats(C.Structure):
                 ("avg_quality", C.c_double)]
 
 
+class MJpegEncoderRateControlCbs(C.Structure):
+    """server/mjpeg_encoder.h:40-44"""
+    _fields_ = [("get_roundtrip_ms", C.c_void_p), ("get_source_fps", C.c_void_p),
+                ("update_client_playback_delay", C.c_void_p)]
+
+
+class SpiceGpuMjpegRateState(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "during_quality_eval", "eval_type", "eval_reason", "min_quality_id", "min_quality_fps",
+        "max_quality_id", "max_quality_fps", "max_sampled_fps", "max_sampled_fps_quality_id",
+        "quality_id")] + [
+        ("fps", C.c_uint32), ("num_recent_enc_frames", C.c_uint32),
+        ("encoded_size_by_quality", C.c_uint64 * 7), ("adjusted_fps", C.c_double),
+        ("adjusted_fps_start_time", C.c_uint64), ("adjusted_fps_num_frames", C.c_uint64),
+        ("byte_rate", C.c_uint64), ("base_enc_size", C.c_uint64), ("last_enc_size", C.c_uint64),
+        ("sum_recent_enc_size", C.c_uint64), ("warmup_start_time", C.c_uint64),
+        ("change_start_time", C.c_uint64), ("last_frame_time", C.c_uint64),
+        ("sum_enc_size", C.c_uint64), ("change_start_mm_time", C.c_uint32),
+        ("num_enc_frames", C.c_uint32), ("was_upgraded", C.c_int32),
+        ("max_video_latency", C.c_int32), ("max_audio_latency", C.c_uint32),
+        ("num_frames_encoded", C.c_uint32), ("num_frames_dropped", C.c_uint32),
+        ("playback_delay_updates", C.c_uint32), ("playback_delay_last", C.c_uint32),
+        ("reserved", C.c_uint32)]
+
+
+_U32_CB = C.CFUNCTYPE(C.c_uint32, C.c_void_p)
+_DELAY_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32)
+_CLOCK_CB = C.CFUNCTYPE(C.c_uint64, C.c_void_p)
+
+
+class StreamEnv:
+    """What a stream's rate controller asks its owner (the StreamAgent of
+    server/red_worker.c:2984-3020): round trip, source frame rate, and where
+    playback-delay updates go.  now_ns, when set, replaces CLOCK_MONOTONIC."""
+
+    def __init__(self, roundtrip_ms=0, source_fps=25, now_ns=None, with_delay_cb=True):
+        self.roundtrip_ms = roundtrip_ms
+        self.source_fps = source_fps
+        self.now_ns = now_ns
+        self.playback_delays = []
+        self._keep = (_U32_CB(lambda _o: self.roundtrip_ms & 0xFFFFFFFF),
+                      _U32_CB(lambda _o: self.source_fps & 0xFFFFFFFF),
+                      _DELAY_CB(lambda _o, ms: self.playback_delays.append(ms)),
+                      _CLOCK_CB(lambda _o: self.now_ns))
+        self.cbs = MJpegEncoderRateControlCbs(
+            C.cast(self._keep[0], C.c_void_p), C.cast(self._keep[1], C.c_void_p),
+            C.cast(self._keep[2], C.c_void_p) if with_delay_cb else None)
+
+    @property
+    def clock(self):
+        return C.cast(self._keep[3], C.c_void_p) if self.now_ns is not None else None
+
+
 EXPORTS = [
     "spice_gpu_init", "spice_gpu_shutdown", "spice_gpu_last_error", "spice_gpu_stream",
     "glz_enc_dictionary_create", "glz_enc_dictionary_destroy", "glz_enc_dictionary_get_size",
@@ -102,6 +155,9 @@ EXPORTS = [
     "mjpeg_encoder_new", "mjpeg_encoder_destroy", "mjpeg_encoder_get_bytes_per_pixel",
     "mjpeg_encoder_start_frame", "mjpeg_encoder_encode_scanline", "mjpeg_encoder_end_frame",
     "mjpeg_encoder_get_bit_rate", "mjpeg_encoder_get_stats",
+    "mjpeg_encoder_client_stream_report", "mjpeg_encoder_notify_server_frame_drop",
+    "spice_gpu_mjpeg_rate_state", "spice_gpu_mjpeg_set_clock", "spice_gpu_mjpeg_rate_only_new",
+    "spice_gpu_mjpeg_rate_feed",
     "jpeg_encoder_create", "jpeg_encoder_destroy", "jpeg_encode",
     "spice_gpu_glz_out_bound", "spice_gpu_glz_encode_batch", "spice_gpu_glz_submit",
     "spice_gpu_glz_finish", "spice_gpu_jpeg_out_bound", "spice_gpu_jpeg_encode_batch",
@@ -153,6 +209,14 @@ class SpiceGpu:
         L.mjpeg_encoder_end_frame.restype, L.mjpeg_encoder_end_frame.argtypes = C.c_size_t, [vp]
         L.mjpeg_encoder_get_bit_rate.restype, L.mjpeg_encoder_get_bit_rate.argtypes = C.c_uint64, [vp]
         L.mjpeg_encoder_get_stats.argtypes = [vp, C.POINTER(MJpegEncoderStats)]
+        L.mjpeg_encoder_client_stream_report.argtypes = [vp, u32, u32, u32, u32, C.c_int32, u32]
+        L.mjpeg_encoder_notify_server_frame_drop.argtypes = [vp]
+        L.spice_gpu_mjpeg_rate_state.argtypes = [vp, C.POINTER(SpiceGpuMjpegRateState)]
+        L.spice_gpu_mjpeg_set_clock.argtypes = [vp, vp, vp]
+        L.spice_gpu_mjpeg_rate_only_new.restype = vp
+        L.spice_gpu_mjpeg_rate_only_new.argtypes = [C.c_uint64, vp, vp, vp, vp]
+        L.spice_gpu_mjpeg_rate_feed.restype = i
+        L.spice_gpu_mjpeg_rate_feed.argtypes = [vp, u32, C.POINTER(C.c_uint64), C.POINTER(i)]
         L.jpeg_encoder_create.restype, L.jpeg_encoder_create.argtypes = vp, [vp]
         L.jpeg_encoder_destroy.argtypes = [vp]
         L.jpeg_encode.restype = i
@@ -364,11 +428,25 @@ class GlzEncoder:
 
 
 class MJpegEncoder:
-    """mjpeg_encoder_new/start_frame/encode_scanline/end_frame (server/mjpeg_encoder.h)."""
+    """mjpeg_encoder_new/start_frame/encode_scanline/end_frame (server/mjpeg_encoder.h).
 
-    def __init__(self, gpu):
+    env (a StreamEnv) switches bit-rate control on, as red_display_create_stream
+    does when the client supports stream reports (server/red_worker.c:3039-3051).
+    rate_only=True makes a controller with no codec behind it (needs no GPU)."""
+
+    def __init__(self, gpu, env=None, starting_bit_rate=0, rate_only=False):
         self.gpu = gpu
-        self.h = gpu.L.mjpeg_encoder_new(0, 0, None, None)
+        self.env = env
+        L = gpu.L
+        if rate_only:
+            self.h = L.spice_gpu_mjpeg_rate_only_new(starting_bit_rate, C.addressof(env.cbs), None,
+                                                     env.clock, None)
+        elif env is not None:
+            self.h = L.mjpeg_encoder_new(1, starting_bit_rate, C.addressof(env.cbs), None)
+            if self.h and env.clock:
+                L.spice_gpu_mjpeg_set_clock(self.h, env.clock, None)
+        else:
+            self.h = L.mjpeg_encoder_new(0, starting_bit_rate, None, None)
         if not self.h:
             raise SpiceGpuError("mjpeg_encoder_new failed: " + gpu.last_error())
         self._dest = C.c_void_p(None)
@@ -384,12 +462,16 @@ class MJpegEncoder:
             self._libc.free(self._dest)
             self._dest = C.c_void_p(None)
 
-    def encode_frame(self, fmt, width, height, rows, stride):
-        """encode_frame of server/red_worker.c:8341-8377: one scanline call per row."""
+    def encode_frame(self, fmt, width, height, rows, stride, mm_time=0):
+        """red_marshall_stream_data's start_frame / encode_frame / end_frame sequence
+        (server/red_worker.c:8438-8463, 8341-8377): one scanline call per row.
+        Returns None when the rate controller drops the frame."""
         L = self.gpu.L
         rows = np.ascontiguousarray(rows, dtype=np.uint8).reshape(-1)
         r = L.mjpeg_encoder_start_frame(self.h, fmt, width, height, C.byref(self._dest),
-                                        C.byref(self._dest_len), 0)
+                                        C.byref(self._dest_len), mm_time)
+        if r == MJPEG_ENCODER_FRAME_DROP:
+            return None
         if r != MJPEG_ENCODER_FRAME_ENCODE_START:
             raise SpiceGpuError("mjpeg_encoder_start_frame returned %d" % r)
         base = rows.ctypes.data
@@ -400,6 +482,108 @@ class MJpegEncoder:
         if n == 0:
             raise SpiceGpuError("mjpeg_encoder_end_frame: " + self.gpu.last_error())
         return np.ctypeslib.as_array(C.cast(self._dest, C.POINTER(C.c_uint8)), shape=(n,)).copy()
+
+    # ---- bit-rate control (server/mjpeg_encoder.h:94-112)
+    def client_stream_report(self, num_frames, num_drops, start_mm, end_mm, end_frame_delay,
+                             audio_delay=0xFFFFFFFF):
+        self.gpu.L.mjpeg_encoder_client_stream_report(self.h, num_frames, num_drops, start_mm, end_mm,
+                                                      end_frame_delay, audio_delay)
+
+    def notify_server_frame_drop(self):
+        self.gpu.L.mjpeg_encoder_notify_server_frame_drop(self.h)
+
+    def bit_rate(self):
+        return self.gpu.L.mjpeg_encoder_get_bit_rate(self.h)
+
+    def stats(self):
+        st = MJpegEncoderStats()
+        self.gpu.L.mjpeg_encoder_get_stats(self.h, C.byref(st))
+        return {"starting_bit_rate": st.starting_bit_rate, "cur_bit_rate": st.cur_bit_rate,
+                "avg_quality": st.avg_quality}
+
+    def rate_state(self):
+        st = SpiceGpuMjpegRateState()
+        self.gpu.L.spice_gpu_mjpeg_rate_state(self.h, C.byref(st))
+        return {n: (list(getattr(st, n)) if n == "encoded_size_by_quality" else getattr(st, n))
+                for n, _ in st._fields_}
+
+    def rate_feed(self, mm_time, size_by_quality_id):
+        """-> (MJPEG_ENCODER_FRAME_DROP | _ENCODE_START, quality): a frame known only by the
+        size it has at each of the 7 qualities"""
+        q = C.c_int(0)
+        r = self.gpu.L.spice_gpu_mjpeg_rate_feed(self.h, mm_time, (C.c_uint64 * 7)(*size_by_quality_id),
+                                                 C.byref(q))
+        return r, q.value
+
+
+class StreamAgent:
+    """One video stream of one client: red_marshall_stream_data's frame gate and
+    encode_frame's walk over the bitmap's chunks (server/red_worker.c:8315-8502).
+
+    Without rate control the agent itself skips frames that come sooner than
+    1/fps after the last one sent (:8423-8431); with it, the encoder decides."""
+
+    MAX_FPS = 30                              # server/red_worker.c: agent->fps = MAX_FPS (:3036)
+
+    def __init__(self, gpu, env=None, starting_bit_rate=0):
+        self.enc = MJpegEncoder(gpu, env=env, starting_bit_rate=starting_bit_rate)
+        self.rate_control = env is not None
+        self.fps = self.MAX_FPS
+        self.last_send_time = 0
+        self.drops_fps = 0
+        self.frames_sent = 0
+        self.size_sent = 0
+
+    def close(self):
+        self.enc.close()
+
+    @staticmethod
+    def _lines(chunks, stride):
+        """red_get_image_line (:8315-8339): rows in memory order, chunk after chunk;
+        a chunk that does not hold whole rows ends the walk"""
+        for c in chunks:
+            c = np.ascontiguousarray(c, dtype=np.uint8).reshape(-1)
+            for off in range(0, c.size, stride):
+                if c.size - off < stride:
+                    yield None
+                    return
+                yield c[off:off + stride]
+
+    def marshall_stream_data(self, fmt, chunks, image_y, stride, src, top_down, mm_time, now_ns):
+        """src = (left, top, right, bottom) inside the bitmap.  Returns the JFIF bytes,
+        None for a frame skipped or dropped (the call still succeeded, :8429,8449), or
+        raises when the reference would return FALSE."""
+        left, top, right, bottom = src
+        if not self.rate_control and now_ns - self.last_send_time < 10**9 // self.fps:
+            self.drops_fps += 1
+            return None
+        width, height = right - left, bottom - top
+        L, e = self.enc.gpu.L, self.enc
+        r = L.mjpeg_encoder_start_frame(e.h, fmt, width, height, C.byref(e._dest), C.byref(e._dest_len),
+                                        mm_time & 0xFFFFFFFF)
+        if r == MJPEG_ENCODER_FRAME_DROP:
+            self.drops_fps += 1
+            return None
+        if r != MJPEG_ENCODER_FRAME_ENCODE_START:
+            raise SpiceGpuError("mjpeg_encoder_start_frame returned %d" % r)
+        lines = self._lines(chunks, stride)
+        skip = top if top_down else image_y - bottom          # encode_frame, :8355-8358
+        for _ in range(skip):
+            next(lines, None)
+        bpp = L.mjpeg_encoder_get_bytes_per_pixel(e.h)
+        for _ in range(height):
+            row = next(lines, None)
+            if row is None:
+                raise SpiceGpuError("encode_frame: the bitmap has too few lines")
+            if L.mjpeg_encoder_encode_scanline(e.h, row.ctypes.data + left * bpp, width) == 0:
+                raise SpiceGpuError("mjpeg_encoder_encode_scanline failed")
+        n = L.mjpeg_encoder_end_frame(e.h)
+        if n == 0:
+            raise SpiceGpuError("mjpeg_encoder_end_frame: " + self.enc.gpu.last_error())
+        self.last_send_time = now_ns
+        self.frames_sent += 1
+        self.size_sent += n
+        return np.ctypeslib.as_array(C.cast(e._dest, C.POINTER(C.c_uint8)), shape=(n,)).copy()
 
 
 class JpegEncoder:

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "jpeg_device.h"
+#include "mjpeg_rate.h"
 #include "runtime.h"
 
 using namespace spicegpu;
@@ -369,13 +370,14 @@ struct MJpegEncoder {
     int format = 0, width = 0, height = 0, bpp = 0;
     int rows_in = 0;
     bool in_frame = false;
+    bool rate_only = false; /* no codec behind it, see spice_gpu_mjpeg_rate_only_new */
     uint8_t **dest = nullptr;
     size_t *dest_len = nullptr;
-    int quality = 70; /* MJPEG_LEGACY_STATIC_QUALITY_ID, server/mjpeg_encoder.c:31-33 */
+    spicegpu::MjpegRate rate;
+    int frame_quality = 0;
     uint64_t starting_bit_rate = 0;
     uint64_t sum_quality = 0;
     uint32_t num_frames = 0;
-    uint64_t last_enc_size = 0;
 };
 
 struct StillJpeg {
@@ -389,11 +391,9 @@ extern "C" {
 MJpegEncoder *mjpeg_encoder_new(int bit_rate_control, uint64_t starting_bit_rate,
                                 MJpegEncoderRateControlCbs *cbs, void *opaque)
 {
-    (void)cbs;
-    (void)opaque;
-    if (bit_rate_control) {
-        set_error("mjpeg: rate control is host policy outside this library; create the encoder "
-                  "with bit_rate_control = 0");
+    /* server/mjpeg_encoder.c:192 asserts this */
+    if (bit_rate_control && !(cbs && cbs->get_roundtrip_ms && cbs->get_source_fps)) {
+        set_error("mjpeg: rate control needs get_roundtrip_ms and get_source_fps");
         return nullptr;
     }
     if (!ensure_init()) {
@@ -401,7 +401,68 @@ MJpegEncoder *mjpeg_encoder_new(int bit_rate_control, uint64_t starting_bit_rate
     }
     MJpegEncoder *e = new MJpegEncoder();
     e->starting_bit_rate = starting_bit_rate;
+    e->rate.init(bit_rate_control != 0, starting_bit_rate, cbs, opaque);
     return e;
+}
+
+MJpegEncoder *spice_gpu_mjpeg_rate_only_new(uint64_t starting_bit_rate,
+                                            MJpegEncoderRateControlCbs *cbs, void *opaque,
+                                            uint64_t (*clock_fn)(void *), void *clock_opaque)
+{
+    if (!(cbs && cbs->get_roundtrip_ms && cbs->get_source_fps)) {
+        set_error("mjpeg: rate control needs get_roundtrip_ms and get_source_fps");
+        return nullptr;
+    }
+    MJpegEncoder *e = new MJpegEncoder();
+    e->rate_only = true;
+    e->starting_bit_rate = starting_bit_rate;
+    e->rate.set_clock(clock_fn, clock_opaque);
+    e->rate.init(true, starting_bit_rate, cbs, opaque);
+    return e;
+}
+
+int spice_gpu_mjpeg_rate_feed(MJpegEncoder *e, uint32_t frame_mm_time,
+                              const uint64_t *size_by_quality_id, int *quality)
+{
+    if (!e->rate.admit_frame(frame_mm_time)) {
+        return MJPEG_ENCODER_FRAME_DROP;
+    }
+    e->frame_quality = e->rate.quality();
+    e->num_frames++;
+    e->sum_quality += (uint64_t)e->frame_quality;
+    if (quality) {
+        *quality = e->frame_quality;
+    }
+    const uint64_t enc_size = size_by_quality_id[(e->frame_quality - 20) / 10];
+    if (enc_size) {
+        e->rate.frame_coded(enc_size);
+    } else {
+        e->rate.frame_aborted();
+    }
+    return MJPEG_ENCODER_FRAME_ENCODE_START;
+}
+
+void spice_gpu_mjpeg_set_clock(MJpegEncoder *e, uint64_t (*clock_fn)(void *), void *opaque)
+{
+    e->rate.set_clock(clock_fn, opaque);
+}
+
+void spice_gpu_mjpeg_rate_state(MJpegEncoder *e, SpiceGpuMjpegRateState *out)
+{
+    e->rate.snapshot(out);
+}
+
+void mjpeg_encoder_client_stream_report(MJpegEncoder *e, uint32_t num_frames, uint32_t num_drops,
+                                        uint32_t start_frame_mm_time, uint32_t end_frame_mm_time,
+                                        int32_t end_frame_delay, uint32_t audio_delay)
+{
+    e->rate.client_report(num_frames, num_drops, start_frame_mm_time, end_frame_mm_time,
+                          end_frame_delay, audio_delay);
+}
+
+void mjpeg_encoder_notify_server_frame_drop(MJpegEncoder *e)
+{
+    e->rate.server_dropped_frame();
 }
 
 void mjpeg_encoder_destroy(MJpegEncoder *e)
@@ -424,7 +485,14 @@ uint8_t mjpeg_encoder_get_bytes_per_pixel(MJpegEncoder *e)
 int mjpeg_encoder_start_frame(MJpegEncoder *e, int format, int width, int height, uint8_t **dest,
                               size_t *dest_len, uint32_t frame_mm_time)
 {
-    (void)frame_mm_time;
+    if (e->rate_only) {
+        set_error("mjpeg: this encoder is a rate controller only");
+        return MJPEG_ENCODER_FRAME_UNSUPPORTED;
+    }
+    /* the rate decision comes first, as in server/mjpeg_encoder.c:736-769 */
+    if (!e->rate.admit_frame(frame_mm_time)) {
+        return MJPEG_ENCODER_FRAME_DROP;
+    }
     /* server/mjpeg_encoder.c:775-801 */
     if (format != SPICE_GPU_BITMAP_FMT_32BIT && format != SPICE_GPU_BITMAP_FMT_RGBA &&
         format != SPICE_GPU_BITMAP_FMT_24BIT && format != SPICE_GPU_BITMAP_FMT_16BIT) {
@@ -445,15 +513,16 @@ int mjpeg_encoder_start_frame(MJpegEncoder *e, int format, int width, int height
         return MJPEG_ENCODER_FRAME_UNSUPPORTED;
     }
     e->in_frame = true;
+    e->frame_quality = e->rate.quality(); /* :821 */
     e->num_frames++;
-    e->sum_quality += (uint64_t)e->quality;
+    e->sum_quality += (uint64_t)e->frame_quality;
     return MJPEG_ENCODER_FRAME_ENCODE_START;
 }
 
 int mjpeg_encoder_encode_scanline(MJpegEncoder *e, uint8_t *src_pixels, size_t image_width)
 {
     if (!e->in_frame || e->rows_in >= e->height || image_width != (size_t)e->width) {
-        e->last_enc_size = 0;
+        e->rate.frame_aborted();
         return 0;
     }
     size_t row = (size_t)e->width * (size_t)e->bpp;
@@ -471,10 +540,10 @@ size_t mjpeg_encoder_end_frame(MJpegEncoder *e)
     }
     e->in_frame = false;
     /* server/mjpeg_encoder.c:819-823: defaults, IFAST, quality, one JFIF per frame */
-    size_t n = encode_host_frame(e->hp, e->format, e->width, e->height, e->quality,
+    size_t n = encode_host_frame(e->hp, e->format, e->width, e->height, e->frame_quality,
                                  SPICE_GPU_DCT_IFAST, SPICE_GPU_STAT_MJPEG);
     if (!n) {
-        e->last_enc_size = 0;
+        e->rate.frame_aborted();
         return 0;
     }
     /* spice_jpeg_mem_dest semantics (server/mjpeg_encoder.c:281-359): the buffer is
@@ -487,6 +556,7 @@ size_t mjpeg_encoder_end_frame(MJpegEncoder *e)
         uint8_t *nb = (uint8_t *)malloc(cap);
         if (!nb) {
             set_error("mjpeg: out of memory");
+            e->rate.frame_aborted();
             return 0;
         }
         free(*e->dest);
@@ -494,13 +564,13 @@ size_t mjpeg_encoder_end_frame(MJpegEncoder *e)
         *e->dest_len = cap;
     }
     memcpy(*e->dest, e->hp.out.ptr, n);
-    e->last_enc_size = n;
+    e->rate.frame_coded(n);
     return n;
 }
 
 uint64_t mjpeg_encoder_get_bit_rate(MJpegEncoder *e)
 {
-    return e->starting_bit_rate; /* byte_rate * 8 with rate control off, mjpeg_encoder.c:198 */
+    return e->rate.bit_rate(); /* byte_rate * 8, server/mjpeg_encoder.c:1260-1263 */
 }
 
 void mjpeg_encoder_get_stats(MJpegEncoder *e, MJpegEncoderStats *stats)
