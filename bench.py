@@ -52,7 +52,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="glz1080", choices=["glz1080", "mjpeg2160"])
-    ap.add_argument("--sessions", type=int, default=1024, help="GLZ display sessions per GPU")
+    ap.add_argument("--sessions", type=int, default=1536, help="GLZ display sessions per GPU")
     ap.add_argument("--frames", type=int, default=16, help="MJPEG frames per step per GPU")
     ap.add_argument("--pool", type=int, default=8, help="distinct synthetic sequences per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -93,20 +93,22 @@ class GlzWorkload:
         self.encs = [B.GlzEncoder(gpu, d, 0) for d in self.dicts]
         self.cap = gpu.L.spice_gpu_glz_out_bound(B.LZ_IMAGE_TYPE_RGB32, W1080, H1080)
         self.outs = [gpu.malloc(self.cap) for _ in range(self.S)]
+        # the job array is built once; a step only swaps in every session's next frame
+        self.plan = B.GlzBatchPlan(gpu, [
+            dict(encoder=self.encs[s], type=B.LZ_IMAGE_TYPE_RGB32, width=W1080, height=H1080,
+                 stride=W1080 * 4, chunks=[self.dev_frames[s % pool][0]], chunk_rows=[H1080],
+                 out=self.outs[s], out_capacity=self.cap) for s in range(self.S)])
+        self.step_ptrs = [np.array([self.dev_frames[s % pool][k] for s in range(self.S)], dtype=np.uint64)
+                          for k in range(self.nframes)]
         self.setup_s = time.time() - t0
         self.k = 0
         self.out_bytes = 0
         self.units_per_step = self.S * W1080 * H1080
 
     def step(self):
-        B, k = self.B, self.k
-        items = [dict(encoder=self.encs[s], type=B.LZ_IMAGE_TYPE_RGB32, width=W1080, height=H1080,
-                      stride=W1080 * 4, chunks=[self.dev_frames[s % self.pool][k]],
-                      chunk_rows=[H1080], out=self.outs[s], out_capacity=self.cap)
-                 for s in range(self.S)]
-        sizes, _ = B.glz_encode_batch(self.gpu, items)
+        sizes = self.plan.run(self.step_ptrs[self.k])
         self.k += 1
-        self.last_out = int(sum(sizes))
+        self.last_out = int(sizes.sum(dtype=np.int64))
         return self.last_out
 
     def config(self, args):

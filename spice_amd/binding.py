@@ -672,6 +672,47 @@ def glz_encode_batch(gpu, items, split=False):
     return [jobs[j].out_size for j in range(n)], [jobs[j].dict_image for j in range(n)]
 
 
+class GlzBatchPlan:
+    """A device-resident batch that is submitted again and again: every job keeps
+    its encoder, geometry and output buffer, only the chunk pointers change (each
+    session's next frame).  Saves rebuilding the job array per call."""
+
+    def __init__(self, gpu, items):
+        self.gpu, self.n = gpu, len(items)
+        self.jobs = (SpiceGpuGlzJob * self.n)()
+        total = sum(len(it["chunks"]) for it in items)
+        self.ptrs = np.zeros(total, dtype=np.uint64)
+        self.rows = np.zeros(total, dtype=np.uint32)
+        off = 0
+        for j, it in enumerate(items):
+            nch = len(it["chunks"])
+            self.ptrs[off:off + nch] = it["chunks"]
+            self.rows[off:off + nch] = it["chunk_rows"]
+            job = self.jobs[j]
+            job.encoder = it["encoder"].h
+            job.type = it["type"]
+            job.width, job.height = it["width"], it["height"]
+            job.top_down, job.stride = int(it.get("top_down", 1)), it["stride"]
+            job.nchunks = nch
+            job.chunk_ptrs = C.cast(self.ptrs.ctypes.data + 8 * off, C.POINTER(C.c_void_p))
+            job.chunk_rows = C.cast(self.rows.ctypes.data + 4 * off, C.POINTER(C.c_uint32))
+            job.out, job.out_capacity = it["out"], it["out_capacity"]
+            job.usr_context = it.get("usr_context", 0)
+            off += nch
+        self._sizes = np.ndarray((self.n,), dtype=np.int32, buffer=self.jobs,
+                                 offset=SpiceGpuGlzJob.out_size.offset,
+                                 strides=(C.sizeof(SpiceGpuGlzJob),))
+
+    def run(self, chunk_ptrs=None):
+        """chunk_ptrs: all jobs' chunk device pointers, flattened in job order.
+        Returns the compressed sizes (numpy int32, one per job)."""
+        if chunk_ptrs is not None:
+            self.ptrs[:] = chunk_ptrs
+        if self.gpu.L.spice_gpu_glz_encode_batch(self.jobs, self.n) != 0:
+            raise SpiceGpuError("glz batch: " + self.gpu.last_error())
+        return self._sizes.copy()
+
+
 def jpeg_encode_batch(gpu, items):
     """Device-resident batch of frames; items are dicts with pixels (device
     pointer), format, width, height, stride, quality, dct, out, out_capacity."""

@@ -16,6 +16,7 @@
  */
 #include <string.h>
 
+#include <algorithm>
 #include <mutex>
 #include <vector>
 
@@ -71,6 +72,9 @@ struct Dict {
     std::vector<uint32_t> encoders_heads;
     HostImage *used_images_head = nullptr, *used_images_tail = nullptr, *free_images = nullptr;
     GlzEncoderUsrContext *cur_usr = nullptr;
+    /* compressed bytes per raw byte of this dictionary's last batch image; 2 until
+     * one exists, so that new sessions count as expensive.  Orders a batch. */
+    double cost_hint = 2.0;
 
     /* HBM side */
     uint8_t *d_arena = nullptr;
@@ -593,7 +597,22 @@ bool launch(std::vector<Prepared> &jobs, Staging &st, size_t *results_off, bool 
     GlzDevJob *dj = (GlzDevJob *)(st.host + off_jobs);
     size_t iu = 0, iup = 0, ic = 0;
     uint64_t max_copy = 0;
+    /* A workgroup parses one image and the hardware starts workgroups in index
+     * order as slots free up, so a batch larger than the GPU holds at once
+     * finishes soonest with the expensive images first.  The expected cost of an
+     * image is its size times what its session's previous image compressed to
+     * (stops per pixel follow the compressed size).  Results keep the callers'
+     * job order. */
+    std::vector<uint32_t> order(n);
+    std::vector<double> cost(n);
     for (size_t j = 0; j < n; j++) {
+        order[j] = (uint32_t)j;
+        cost[j] = (double)jobs[j].raw_bytes * (jobs[j].enc ? jobs[j].enc->dict->cost_hint : 1.0);
+    }
+    std::stable_sort(order.begin(), order.end(),
+                     [&cost](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+    for (size_t pos = 0; pos < n; pos++) {
+        const size_t j = order[pos];
         Prepared &p = jobs[j];
         p.dev.seg_list_off = (uint32_t)iu;
         p.dev.upd_off = (uint32_t)iup;
@@ -604,7 +623,7 @@ bool launch(std::vector<Prepared> &jobs, Staging &st, size_t *results_off, bool 
             cp[ic++] = c;
             max_copy = c.bytes > max_copy ? c.bytes : max_copy;
         }
-        dj[j] = p.dev;
+        dj[pos] = p.dev;
     }
     hipStream_t s = stream();
     if (!check(hipMemcpyAsync(st.dev, st.host, off_res, hipMemcpyHostToDevice, s), "upload jobs")) {
@@ -990,6 +1009,7 @@ int spice_gpu_glz_finish(SpiceGpuGlzJob *jobs, int njobs)
         } else {
             stat_add(SPICE_GPU_STAT_GLZ, f.jobs[(size_t)j].raw_bytes, (uint64_t)jobs[j].out_size,
                      dt / (uint64_t)njobs);
+            e->dict->cost_hint = (double)jobs[j].out_size / (double)f.jobs[(size_t)j].raw_bytes;
         }
     }
     f.dict_locks.clear();

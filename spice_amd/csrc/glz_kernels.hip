@@ -1575,7 +1575,10 @@ __device__ __forceinline__ void glz_parse_image(const GlzDevJob &job, const uint
 /* One workgroup per job: apply the window-table updates, write the header
  * (glz_encoder.c:264-276), parse, report the size. */
 template <int TYPE>
-__global__ void __launch_bounds__(GLZ_THREADS)
+/* Six workgroups per CU (80 VGPRs, a few spilled dwords): a session's parse is
+ * bound by its own latency chain, so the GPU's throughput is the number of
+ * sessions it holds at once. */
+__global__ void __launch_bounds__(GLZ_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6)))
 glz_parse_kernel(const GlzDevJob *__restrict__ jobs, const uint32_t *__restrict__ u32_pool,
                  const GlzDevSegUpdate *__restrict__ upd_pool)
 {

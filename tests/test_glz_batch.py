@@ -1,0 +1,143 @@
+"""The device-resident batch interface (spice_gpu_glz_encode_batch): many
+sessions, one image each per call, pixels already in device memory and streams
+left there.  Every session's stream is compared with the CPU oracle's, frame
+after frame.  The library starts a batch's workgroups in the order of expected
+cost, so the cases mix cheap and expensive sessions and check that results
+still come back in the caller's job order."""
+import numpy as np
+import pytest
+
+from spice_amd import binding as B
+from spice_amd import frames
+
+from helpers import assert_same_stream, pixels_for, small_desktop, split_rows
+
+
+class Session:
+    def __init__(self, dev, oracle, typ, w, h, kind, seed, window, nchunks=1):
+        self.dev, self.typ, self.w, self.h, self.kind, self.nchunks = dev, typ, w, h, kind, nchunks
+        self.rng = np.random.default_rng(seed)
+        self.seq = frames.DesktopSequence(max(w, 96), max(h, 96), seed)
+        self.od = oracle.GlzDict(window, 1)
+        self.gd = B.GlzDictionary(dev, window, 1)
+        self.ge = B.GlzEncoder(dev, self.gd, 0)
+        self.cap = dev.L.spice_gpu_glz_out_bound(typ, w, h)
+        self.out = dev.malloc(self.cap)
+        self.held = []
+
+    def next_image(self):
+        if self.kind == "noise":
+            im = np.zeros((self.h, self.w, 4), np.uint8)
+            im[..., :3] = self.rng.integers(0, 256, (self.h, self.w, 3))
+        elif self.kind == "flat":
+            im = np.zeros((self.h, self.w, 4), np.uint8)
+            im[..., :3] = self.rng.integers(0, 256, 3)
+        else:
+            im = self.seq.next()[:self.h, :self.w].copy()
+        px = pixels_for(self.typ, im, self.rng)
+        self.stride = px.shape[1]
+        self.chunks = split_rows(px, self.nchunks)
+        self.held = [self.dev.to_device(c) for c in self.chunks]
+        return dict(encoder=self.ge, type=self.typ, width=self.w, height=self.h, stride=self.stride,
+                    chunks=self.held, chunk_rows=[c.shape[0] for c in self.chunks], out=self.out,
+                    out_capacity=self.cap)
+
+    def check(self, size, what):
+        want, _ = self.od.encode(self.typ, self.w, self.h, self.stride, self.chunks)
+        got = self.dev.download(self.out, size)
+        assert_same_stream(want, got, what)
+        for p in self.held:
+            self.dev.free(p)
+
+    def close(self):
+        self.dev.free(self.out)
+        self.ge.close()
+        self.gd.close()
+        self.od.close()
+
+
+def run_batches(dev, oracle, specs, nframes, window):
+    sessions = [Session(dev, oracle, *spec, seed=31 + k, window=window) for k, spec in enumerate(specs)]
+    try:
+        for f in range(nframes):
+            items = [s.next_image() for s in sessions]
+            sizes, _ = B.glz_encode_batch(dev, items, split=bool(f % 2))
+            for k, (s, n) in enumerate(zip(sessions, sizes)):
+                assert n > 0
+                s.check(n, "batch frame %d session %d (%s)" % (f, k, s.kind))
+    finally:
+        for s in sessions:
+            s.close()
+
+
+SMALL = [(B.LZ_IMAGE_TYPE_RGB32, 96, 40, "desktop"), (B.LZ_IMAGE_TYPE_RGB32, 64, 64, "noise"),
+         (B.LZ_IMAGE_TYPE_RGBA, 80, 30, "desktop"), (B.LZ_IMAGE_TYPE_RGB16, 120, 20, "flat"),
+         (B.LZ_IMAGE_TYPE_RGB24, 33, 17, "desktop"), (B.LZ_IMAGE_TYPE_RGB32, 7, 3, "noise"),
+         (B.LZ_IMAGE_TYPE_RGB32, 200, 30, "flat")]
+
+
+def test_sim_batch_of_mixed_sessions(sim, oracle):
+    run_batches(sim, oracle, SMALL, 4, window=1 << 15)
+
+
+def test_sim_two_jobs_on_one_dictionary_are_refused(sim, oracle):
+    s = Session(sim, oracle, B.LZ_IMAGE_TYPE_RGB32, 32, 8, "flat", seed=1, window=1 << 12)
+    try:
+        it = s.next_image()
+        with pytest.raises(B.SpiceGpuError, match="share a dictionary"):
+            B.glz_encode_batch(sim, [it, dict(it)])
+    finally:
+        s.close()
+
+
+def run_plan(dev, oracle, n, w, h, nframes, window):
+    """GlzBatchPlan: the job array is built once and only the frame pointers change"""
+    seqs = [frames.DesktopSequence(max(w, 96), max(h, 96), seed=70 + k) for k in range(n)]
+    ods = [oracle.GlzDict(window, 1) for _ in range(n)]
+    gds = [B.GlzDictionary(dev, window, 1) for _ in range(n)]
+    ges = [B.GlzEncoder(dev, d, 0) for d in gds]
+    cap = dev.L.spice_gpu_glz_out_bound(B.LZ_IMAGE_TYPE_RGB32, w, h)
+    outs = [dev.malloc(cap) for _ in range(n)]
+    imgs = [[np.ascontiguousarray(s.next()[:h, :w]).reshape(h, -1) for _ in range(nframes)] for s in seqs]
+    if n > 2:                      # one session far cheaper, one far dearer than the rest
+        imgs[1] = [np.zeros_like(im) for im in imgs[1]]
+        rng = np.random.default_rng(5)
+        imgs[2] = [rng.integers(0, 256, im.shape, dtype=np.uint8) for im in imgs[2]]
+    dev_imgs = [[dev.to_device(im) for im in row] for row in imgs]
+    try:
+        plan = B.GlzBatchPlan(dev, [dict(encoder=ges[k], type=B.LZ_IMAGE_TYPE_RGB32, width=w, height=h,
+                                         stride=w * 4, chunks=[dev_imgs[k][0]], chunk_rows=[h],
+                                         out=outs[k], out_capacity=cap) for k in range(n)])
+        for f in range(nframes):
+            sizes = plan.run(np.array([dev_imgs[k][f] for k in range(n)], dtype=np.uint64))
+            for k in range(n):
+                want, _ = ods[k].encode(B.LZ_IMAGE_TYPE_RGB32, w, h, w * 4, [imgs[k][f]])
+                assert_same_stream(want, dev.download(outs[k], int(sizes[k])),
+                                   "plan frame %d session %d" % (f, k))
+    finally:
+        for row in dev_imgs:
+            for p in row:
+                dev.free(p)
+        for k in range(n):
+            dev.free(outs[k])
+            ges[k].close()
+            gds[k].close()
+            ods[k].close()
+
+
+def test_sim_batch_plan(sim, oracle):
+    run_plan(sim, oracle, 4, 96, 48, 3, window=1 << 15)
+
+
+@pytest.mark.gpu
+def test_gpu_batch_of_mixed_sessions(gpu, oracle):
+    big = SMALL + [(B.LZ_IMAGE_TYPE_RGB32, 640, 400, "desktop"), (B.LZ_IMAGE_TYPE_RGB32, 320, 200, "noise"),
+                   (B.LZ_IMAGE_TYPE_RGBA, 300, 300, "desktop"), (B.LZ_IMAGE_TYPE_RGB32, 1024, 64, "flat")]
+    run_batches(gpu, oracle, big, 6, window=1 << 19)
+
+
+@pytest.mark.gpu
+def test_gpu_batch_plan_1080p(gpu, oracle):
+    """BASELINE configs[1] through the interface bench.py measures: 24 sessions of
+    1920x1080 desktop frames, 16 Mi-pixel windows"""
+    run_plan(gpu, oracle, 24, 1920, 1080, 4, window=16 * 1024 * 1024)
