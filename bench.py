@@ -52,7 +52,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="glz1080", choices=["glz1080", "mjpeg2160"])
-    ap.add_argument("--sessions", type=int, default=1536, help="GLZ display sessions per GPU")
+    ap.add_argument("--sessions", type=int, default=2048, help="GLZ display sessions per GPU")
     ap.add_argument("--frames", type=int, default=16, help="MJPEG frames per step per GPU")
     ap.add_argument("--pool", type=int, default=8, help="distinct synthetic sequences per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")

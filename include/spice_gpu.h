@@ -112,6 +112,18 @@ void glz_enc_dictionary_reset(GlzEncDictContext *opaque_dict, GlzEncoderUsrConte
 void glz_enc_dictionary_remove_image(GlzEncDictContext *opaque_dict,
                                      GlzEncDictImageContext *image, GlzEncoderUsrContext *usr);
 
+/* What a dictionary holds in device memory.  No counterpart in the reference,
+ * whose window points into guest RAM (server/glz_encoder_dictionary.c:469). */
+typedef struct SpiceGpuGlzDictInfo {
+    uint64_t arena_bytes;   /* pixel copies of the window's images */
+    uint64_t table_bytes;   /* hash table + segment table */
+    uint32_t images;        /* images in the window */
+    uint32_t segments;      /* segment slots, used and free */
+    uint32_t window_pixels; /* pixels of those images */
+    uint32_t arena_regrows; /* times the arena was re-made larger */
+} SpiceGpuGlzDictInfo;
+void spice_gpu_glz_dictionary_info(GlzEncDictContext *opaque_dict, SpiceGpuGlzDictInfo *out);
+
 /* server/glz_encoder.h:30-33 */
 GlzEncoderContext *glz_encoder_create(uint8_t id, GlzEncDictContext *dictionary,
                                       GlzEncoderUsrContext *usr);

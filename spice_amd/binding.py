@@ -85,6 +85,11 @@ class SpiceGpuCodecStats(C.Structure):
                 ("total_ns", C.c_uint64), ("min_ns", C.c_uint64), ("max_ns", C.c_uint64)]
 
 
+class SpiceGpuGlzDictInfo(C.Structure):
+    _fields_ = [("arena_bytes", C.c_uint64), ("table_bytes", C.c_uint64), ("images", C.c_uint32),
+                ("segments", C.c_uint32), ("window_pixels", C.c_uint32), ("arena_regrows", C.c_uint32)]
+
+
 class SpiceGpuKernelTime(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double)]
 
@@ -151,7 +156,7 @@ EXPORTS = [
     "spice_gpu_init", "spice_gpu_shutdown", "spice_gpu_last_error", "spice_gpu_stream",
     "glz_enc_dictionary_create", "glz_enc_dictionary_destroy", "glz_enc_dictionary_get_size",
     "glz_enc_dictionary_get_restore_data", "glz_enc_dictionary_restore", "glz_enc_dictionary_reset",
-    "glz_enc_dictionary_remove_image", "glz_encoder_create", "glz_encoder_destroy", "glz_encode",
+    "glz_enc_dictionary_remove_image", "spice_gpu_glz_dictionary_info", "glz_encoder_create", "glz_encoder_destroy", "glz_encode",
     "mjpeg_encoder_new", "mjpeg_encoder_destroy", "mjpeg_encoder_get_bytes_per_pixel",
     "mjpeg_encoder_start_frame", "mjpeg_encoder_encode_scanline", "mjpeg_encoder_end_frame",
     "mjpeg_encoder_get_bit_rate", "mjpeg_encoder_get_stats",
@@ -193,6 +198,7 @@ class SpiceGpu:
         L.glz_enc_dictionary_restore.argtypes = [C.POINTER(GlzEncDictRestoreData), vp]
         L.glz_enc_dictionary_reset.argtypes = [vp, vp]
         L.glz_enc_dictionary_remove_image.argtypes = [vp, vp, vp]
+        L.spice_gpu_glz_dictionary_info.argtypes = [vp, C.POINTER(SpiceGpuGlzDictInfo)]
         L.glz_encoder_create.restype, L.glz_encoder_create.argtypes = vp, [C.c_uint8, vp, vp]
         L.glz_encoder_destroy.argtypes = [vp]
         L.glz_encode.restype = i
@@ -387,6 +393,12 @@ class GlzDictionary:
 
     def reset(self):
         self.gpu.L.glz_enc_dictionary_reset(self.h, self.usr.ptr)
+
+    def info(self):
+        """device memory held by this dictionary (spice_gpu_glz_dictionary_info)"""
+        st = SpiceGpuGlzDictInfo()
+        self.gpu.L.spice_gpu_glz_dictionary_info(self.h, C.byref(st))
+        return {n: getattr(st, n) for n, _ in st._fields_}
 
     def remove_image(self, image):
         self.gpu.L.glz_enc_dictionary_remove_image(self.h, image, self.usr.ptr)

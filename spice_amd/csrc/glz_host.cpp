@@ -87,6 +87,8 @@ struct Dict {
     /* FIFO ring allocator over the arena */
     uint64_t ring_head = 0, ring_tail = 0;
     bool ring_wrapped = false;
+    uint64_t largest_run = 0; /* most arena bytes one image has taken so far */
+    uint32_t arena_regrows = 0;
 };
 
 struct Encoder {
@@ -144,6 +146,69 @@ void ring_after_free(Dict *d, uint64_t freed_begin)
         d->ring_wrapped = false;
     }
     d->ring_head = nh;
+}
+
+uint64_t arena_slack(uint32_t window_px)
+{
+    /* 16-byte alignment of every segment, with a floor for small windows */
+    uint64_t s = (uint64_t)window_px * 4 / 16;
+    return s < (64u << 10) ? (64u << 10) : s;
+}
+
+void mark_image_dirty(Dict *d, HostImage *im);
+
+/* A FIFO of contiguous runs wastes at most one run where it wraps, so an arena
+ * of the window's bytes plus the largest run always has room for the next
+ * image once the images it displaces are gone.  The arena starts at the
+ * window's size and is re-made to that bound the first time an image does not
+ * fit: live images move to the front of the new arena in window order (their
+ * segments' offsets change and are uploaded again with the next job). */
+bool arena_regrow(Dict *d, uint64_t need)
+{
+    uint64_t live = 0;
+    for (HostImage *im = d->used_images_head; im; im = im->next) {
+        live += im->arena_end - im->arena_begin;
+        uint64_t run = im->arena_end - im->arena_begin;
+        d->largest_run = run > d->largest_run ? run : d->largest_run;
+    }
+    d->largest_run = need > d->largest_run ? need : d->largest_run;
+    uint64_t cap = (uint64_t)d->size_limit * 4 + d->largest_run + arena_slack(d->size_limit);
+    if (cap < live + 2 * d->largest_run) {
+        cap = live + 2 * d->largest_run; /* eviction held back by another encoder */
+    }
+    uint8_t *fresh = nullptr;
+    if (!check(hipMalloc((void **)&fresh, cap + 64), "hipMalloc arena")) {
+        return false;
+    }
+    hipStream_t st = stream();
+    uint64_t pos = 0;
+    bool ok = true;
+    for (HostImage *im = d->used_images_head; im && ok; im = im->next) {
+        const uint64_t len = im->arena_end - im->arena_begin;
+        ok = check(hipMemcpyAsync(fresh + pos, d->d_arena + im->arena_begin, len,
+                                  hipMemcpyDeviceToDevice, st), "move window image");
+        for (uint32_t sid = im->first_seg; sid != kNullSeg && d->segs[sid].image == im;
+             sid = d->segs[sid].next) {
+            d->segs[sid].arena_off = d->segs[sid].arena_off - im->arena_begin + pos;
+        }
+        mark_image_dirty(d, im);
+        im->arena_begin = pos;
+        im->arena_end = pos + len;
+        pos += len;
+    }
+    ok = ok && check(hipStreamSynchronize(st), "sync");
+    if (!ok) {
+        hipFree(fresh); /* offsets are stale now: the dictionary must be reset by its owner */
+        return false;
+    }
+    hipFree(d->d_arena);
+    d->d_arena = fresh;
+    d->arena_cap = cap;
+    d->ring_head = 0;
+    d->ring_tail = pos;
+    d->ring_wrapped = false;
+    d->arena_regrows++;
+    return true;
 }
 
 /* -------------------------------------------------- device view of a segment */
@@ -459,7 +524,7 @@ const char *prepare(Encoder *enc, LzImageType type, int width, int height, int t
         }
     }
     uint64_t at = 0;
-    if (!ring_alloc(d, need, &at)) {
+    if (!ring_alloc(d, need, &at) && !(arena_regrow(d, need) && ring_alloc(d, need, &at))) {
         return "window arena exhausted\n";
     }
 
@@ -681,9 +746,9 @@ GlzEncDictContext *glz_enc_dictionary_create(uint32_t size, uint32_t max_encoder
     d->max_encoders = max_encoders;
     d->segs.resize(kInitSegs);
     d->encoders_heads.assign(max_encoders, kNullSeg);
-    /* FIFO ring: twice the window (in its widest pixel format) always has room
-     * for the next image once the head images it displaces are gone */
-    d->arena_cap = 2ull * (uint64_t)size * 4ull + (4ull << 20);
+    /* FIFO ring: the window in its widest pixel format; re-made larger by
+     * arena_regrow the first time the ring's wrap point wastes too much */
+    d->arena_cap = (uint64_t)size * 4ull + arena_slack(size);
     bool ok = check(hipMalloc((void **)&d->d_arena, d->arena_cap + 64), "hipMalloc arena") &&
               check(hipMalloc((void **)&d->d_htab, sizeof(uint2) * (size_t)GLZ_HASH_SIZE), "hipMalloc htab");
     ok = ok && ensure_dev_segs(d);
@@ -760,6 +825,21 @@ void glz_enc_dictionary_remove_image(GlzEncDictContext *opaque_dict,
     if (im->alive) {
         im->alive = false; /* glz_encoder_dictionary.c:142-145 */
         mark_image_dirty(d, im);
+    }
+}
+
+void spice_gpu_glz_dictionary_info(GlzEncDictContext *opaque_dict, SpiceGpuGlzDictInfo *out)
+{
+    Dict *d = (Dict *)opaque_dict;
+    std::lock_guard<std::recursive_mutex> lock(d->lock);
+    memset(out, 0, sizeof(*out));
+    out->arena_bytes = d->arena_cap;
+    out->table_bytes = sizeof(uint2) * (uint64_t)GLZ_HASH_SIZE + sizeof(GlzDevSeg) * (uint64_t)d->d_segs_cap;
+    out->segments = (uint32_t)d->segs.size();
+    out->arena_regrows = d->arena_regrows;
+    for (HostImage *im = d->used_images_head; im; im = im->next) {
+        out->images++;
+        out->window_pixels += (uint32_t)im->size;
     }
 }
 

@@ -8,7 +8,7 @@ import pytest
 
 from spice_amd import binding as B
 
-from helpers import assert_same_stream, pixels_for, small_desktop, split_rows
+from helpers import GlzPair, assert_same_stream, pixels_for, small_desktop, split_rows
 
 T32 = B.LZ_IMAGE_TYPE_RGB32
 
@@ -105,3 +105,40 @@ def test_sim_dictionary(sim, oracle, case):
 @pytest.mark.parametrize("case", CASES, ids=lambda f: f.__name__)
 def test_gpu_dictionary(gpu, oracle, case):
     case(gpu, oracle)
+
+
+def run_arena_regrow(dev, oracle):
+    """images of growing size through a small window: the window's pixel copies
+    live in a FIFO ring of one window's bytes, which is re-made larger (live images
+    moved) once the wasted run at its wrap point leaves no room.  Streams must
+    not notice."""
+    typ = B.LZ_IMAGE_TYPE_RGB32
+    window = 200000
+    pair = GlzPair(dev, oracle, window)
+    rng = np.random.default_rng(8)
+    try:
+        before = pair.gd.info()
+        assert before["arena_bytes"] == window * 4 + 65536 and before["arena_regrows"] == 0
+        # the sixth image finds 132 KB + 272 KB free, in two pieces, and needs 396 KB in one
+        heights = [200, 150, 280, 150, 330, 330, 330, 320, 250, 150, 330, 100]
+        for k, h in enumerate(heights):
+            flat = np.zeros((h, 300, 4), np.uint8)
+            flat[..., :3] = small_desktop(300, 96, k // 3)[(np.arange(h) * 7) % 96][..., :3]
+            px = pixels_for(typ, flat, rng)
+            pair.encode(typ, 300, h, 1200, split_rows(px, 1 + k % 3), what="regrow %d" % k)
+            info = pair.gd.info()
+            assert info["window_pixels"] <= window and info["images"] >= 1
+            assert info["arena_regrows"] == (0 if k < 5 else 1), k
+        after = pair.gd.info()
+        assert before["arena_bytes"] < after["arena_bytes"] <= 2 * window * 4 + 65536
+    finally:
+        pair.close()
+
+
+def test_sim_arena_regrow(sim, oracle):
+    run_arena_regrow(sim, oracle)
+
+
+@pytest.mark.gpu
+def test_gpu_arena_regrow(gpu, oracle):
+    run_arena_regrow(gpu, oracle)
