@@ -340,14 +340,19 @@ __device__ __forceinline__ void jpeg_load_tiles(const JpegDevJob &job, uint8_t *
 template <bool IFAST>
 __device__ void jpeg_strip_body(const JpegDevJob &job, const uint32_t *huff_g, int group)
 {
-    __shared__ __align__(16) uint8_t ytile[16 * YT_STRIDE];
-    __shared__ __align__(16) uint8_t cbtile[8 * CT_STRIDE];
-    __shared__ __align__(16) uint8_t crtile[8 * CT_STRIDE];
+    /* the pixel tiles are dead once every lane holds its block in registers, so the
+     * coefficients take their place: 37 KB per workgroup, four workgroups per CU */
+    constexpr int kTileBytes = 16 * YT_STRIDE + 2 * 8 * CT_STRIDE;
+    constexpr int kCoefBytes = JG_MCUS * 6 * JCOEF_STRIDE * 4;
+    __shared__ __align__(16) uint8_t pool[kCoefBytes > kTileBytes ? kCoefBytes : kTileBytes];
+    uint8_t *const ytile = pool;
+    uint8_t *const cbtile = pool + 16 * YT_STRIDE;
+    uint8_t *const crtile = cbtile + 8 * CT_STRIDE;
+    uint32_t *const coef = (uint32_t *)pool;
     __shared__ int dcq[JSLOTS * 6];
     __shared__ uint32_t huff[JHUFF_WORDS];
     __shared__ int divs[128];                 /* divisors, luma then chroma */
     __shared__ float rcps[128];
-    __shared__ uint32_t coef[JG_MCUS * 6 * JCOEF_STRIDE];
     __shared__ uint32_t rings[(JT / 64) * JRING_WORDS];
 
     const int tid = (int)threadIdx.x;
@@ -442,6 +447,7 @@ __device__ void jpeg_strip_body(const JpegDevJob &job, const uint32_t *huff_g, i
     if (slot == 0 && !has_halo) {
         have = false;
     }
+    __syncthreads(); /* last read of the tiles; the coefficients overwrite them */
     if (have && real) {
         jpeg_fdct<IFAST>(c);
         const int *dv = divs + (bidx < 4 ? 0 : 64);
@@ -479,6 +485,22 @@ __device__ void jpeg_strip_body(const JpegDevJob &job, const uint32_t *huff_g, i
         }
     }
     __syncthreads();
+    /* DC differences replace the DC values in the coefficient store (jchuff.c
+     * encode_one_block codes the difference to the previous block of the same
+     * component; the four luma blocks of an MCU chain through each other) */
+    if (tid < nm * 6) {
+        const int bslot = tid / 6 + 1, bi = tid - (bslot - 1) * 6;
+        int pred;
+        if (bi == 0) {
+            pred = (bslot == 1 && !has_halo) ? 0 : dcq[(bslot - 1) * 6 + 3];
+        } else if (bi < 4) {
+            pred = dcq[bslot * 6 + bi - 1];
+        } else {
+            pred = (bslot == 1 && !has_halo) ? 0 : dcq[(bslot - 1) * 6 + bi];
+        }
+        ((uint16_t *)coef)[tid * (JCOEF_STRIDE * 2)] = (uint16_t)(dcq[bslot * 6 + bi] - pred);
+    }
+    __syncthreads();
 
     /* ---- phase 3: Huffman, one wavefront per strip */
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63; /* scalar: the loop below is uniform */
@@ -495,21 +517,11 @@ __device__ void jpeg_strip_body(const JpegDevJob &job, const uint32_t *huff_g, i
         const uint32_t zrl = huff[0xf0], zrl_c = huff[256 + 0xf0];
         int vnext = m0 < m1 ? (int)(int16_t)coef16[m0 * 6 * (JCOEF_STRIDE * 2) + lane] : 0;
         for (int b = m0 * 6; b < m1 * 6; b++) {
-            const int bslot = b / 6 + 1, bi = b - (bslot - 1) * 6;
-            int v = vnext;
+            const int bi = b % 6;
+            const int v = vnext;
             if (b + 1 < m1 * 6) {
                 vnext = (int)(int16_t)coef16[(b + 1) * (JCOEF_STRIDE * 2) + lane];
             }
-            /* DC difference, jchuff.c encode_one_block; every lane reads the same words */
-            int pred;
-            if (bi == 0) {
-                pred = (bslot == 1 && !has_halo) ? 0 : dcq[(bslot - 1) * 6 + 3];
-            } else if (bi < 4) {
-                pred = dcq[bslot * 6 + bi - 1];
-            } else {
-                pred = (bslot == 1 && !has_halo) ? 0 : dcq[(bslot - 1) * 6 + bi];
-            }
-            v = lane == 0 ? dcq[bslot * 6 + bi] - pred : v;
             const int ac_off = bi < 4 ? 0 : 256, dc_off = bi < 4 ? 512 : 528;
 
             /* one code per lane: DC (lane 0), a non-zero AC coefficient with the
