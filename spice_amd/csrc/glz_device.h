@@ -57,7 +57,8 @@ struct GlzDevJob {
     uint32_t win_head_dist;
     uint32_t nsegs, seg_list_off;   /* into the u32 pool */
     uint32_t nupd, upd_off;         /* into the update pool */
-    uint32_t pad;
+    uint32_t own_seg;               /* with own_src: the image's only segment ... */
+    const uint8_t *own_src;         /* ... is read from here, not from the arena (or NULL) */
 };
 
 struct GlzCopyDesc {

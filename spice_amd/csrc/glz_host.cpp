@@ -488,7 +488,7 @@ const char *validate(LzImageType type, int width, int height, int stride)
  * description.  Called with the dictionary locked. */
 const char *prepare(Encoder *enc, LzImageType type, int width, int height, int top_down,
                     int stride, const std::vector<Chunk> &chunks, GlzUsrImageContext *usr_context,
-                    uint8_t *d_out, uint32_t out_cap, Prepared *p)
+                    uint8_t *d_out, uint32_t out_cap, bool device_src, Prepared *p)
 {
     Dict *d = enc->dict;
     d->cur_usr = enc->usr;
@@ -619,6 +619,12 @@ const char *prepare(Encoder *enc, LzImageType type, int width, int height, int t
     p->dev.win_head_dist = head_dist;
     p->dev.nsegs = (uint32_t)p->seg_list.size();
     p->dev.nupd = (uint32_t)p->updates.size();
+    /* an image of one chunk that is already in device memory is parsed where it
+     * lies; its copy into the arena only serves later images */
+    if (device_src && p->seg_list.size() == 1 && ((uintptr_t)chunks[0].ptr & 15) == 0) {
+        p->dev.own_src = chunks[0].ptr;
+        p->dev.own_seg = p->seg_list[0];
+    }
     return nullptr;
 }
 
@@ -694,11 +700,21 @@ bool launch(std::vector<Prepared> &jobs, Staging &st, size_t *results_off, bool 
     if (!check(hipMemcpyAsync(st.dev, st.host, off_res, hipMemcpyHostToDevice, s), "upload jobs")) {
         return false;
     }
-    if (copy_on_device && n_copy) {
-        uint64_t per_block = 256ull * 16 * 8; /* 8 vectors per lane */
-        unsigned blocks = (unsigned)((max_copy + per_block - 1) / per_block);
-        blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+    /* When every image of the batch is parsed from its caller's buffer, the copies
+     * into the arenas run on the side stream beside the parse; stream() waits
+     * for them at the end, so whoever synchronises it has both. */
+    bool beside = copy_on_device && n_copy != 0;
+    for (Prepared &p : jobs) {
+        beside = beside && p.dev.own_src != nullptr;
+    }
+    uint64_t per_block = 256ull * 16 * 8; /* 8 vectors per lane */
+    unsigned blocks = (unsigned)((max_copy + per_block - 1) / per_block);
+    blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+    if (copy_on_device && n_copy && !beside) {
         glz_launch_copy((const GlzCopyDesc *)(st.dev + off_copy), (int)n_copy, blocks, s);
+    }
+    if (beside && !check(hipEventRecord(fork_event(), s), "event")) {
+        return false;
     }
     unsigned type_mask = 0;
     for (Prepared &p : jobs) {
@@ -707,11 +723,26 @@ bool launch(std::vector<Prepared> &jobs, Staging &st, size_t *results_off, bool 
     glz_launch_parse((const GlzDevJob *)(st.dev + off_jobs), (int)n, type_mask,
                      (const uint32_t *)(st.dev + off_u32),
                      (const GlzDevSegUpdate *)(st.dev + off_upd), s);
+    if (beside) {
+        /* after the parse, so that the parse's workgroups take their places first
+         * and the copy fills what is left of the CUs */
+        hipStream_t cs = side_stream();
+        if (!check(hipStreamWaitEvent(cs, fork_event(), 0), "wait event")) {
+            return false;
+        }
+        glz_launch_copy((const GlzCopyDesc *)(st.dev + off_copy), (int)n_copy, blocks, cs);
+        if (!check(hipEventRecord(join_event(), cs), "event")) {
+            return false;
+        }
+    }
     if (!check(hipGetLastError(), "glz launch")) {
         return false;
     }
     if (!check(hipMemcpyAsync(st.host + off_res, st.dev + off_res, sizeof(int32_t) * n,
                               hipMemcpyDeviceToHost, s), "download results")) {
+        return false;
+    }
+    if (beside && !check(hipStreamWaitEvent(s, join_event(), 0), "wait event")) {
         return false;
     }
     *results_off = off_res;
@@ -930,7 +961,7 @@ int glz_encode(GlzEncoderContext *opaque_encoder, LzImageType type, int width, i
     }
     std::vector<Prepared> jobs(1);
     const char *err = prepare(enc, type, width, height, top_down, stride, chunks, usr_context,
-                              enc->out.ptr, (uint32_t)bound, &jobs[0]);
+                              enc->out.ptr, (uint32_t)bound, false, &jobs[0]);
     if (err) {
         usr_error(enc->usr, err);
         return 0;
@@ -1035,7 +1066,8 @@ int spice_gpu_glz_submit(SpiceGpuGlzJob *jobs, int njobs)
                 chunks.push_back(Chunk{(const uint8_t *)job.chunk_ptrs[c], job.chunk_rows[c]});
             }
             err = prepare(enc, job.type, job.width, job.height, job.top_down, job.stride, chunks,
-                          job.usr_context, (uint8_t *)job.out, job.out_capacity, &f.jobs[(size_t)j]);
+                          job.usr_context, (uint8_t *)job.out, job.out_capacity, true,
+                          &f.jobs[(size_t)j]);
             if (!err) {
                 job.dict_image = (GlzEncDictImageContext *)f.jobs[(size_t)j].image;
             }

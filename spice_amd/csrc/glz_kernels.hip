@@ -287,8 +287,8 @@ __device__ __forceinline__ int glz_agree4(const glz_u32x4 a, const glz_u32x4 b, 
 
 /* Number of leading positions k in [start, maxn) with src[sidx+k] == ref[ridx+k],
  * plus start.  One wavefront; every load of an iteration is in flight before
- * the first compare.  Lanes past maxn re-read the last valid group (the arena
- * is padded, so a group may run a few pixels over its segment). */
+ * the first compare.  Lanes past the end re-read the last whole group; no
+ * byte beyond position maxn - 1 of either side is touched. */
 template <int MODE>
 __device__ __forceinline__ int glz_match_len(const GLZ_GLOBAL uint8_t *sbase, int sidx,
                                              const GLZ_GLOBAL uint8_t *rbase, int ridx, int start,
@@ -298,13 +298,14 @@ __device__ __forceinline__ int glz_match_len(const GLZ_GLOBAL uint8_t *sbase, in
     int n = start;
     if (MODE == GLZ_MODE_RGB32 || MODE == GLZ_MODE_ALPHA) {
         const uint32_t mask = glz_raw_mask<MODE>();
-        while (n < maxn) {
+        const int lim = maxn - 3; /* a group of four never reaches past maxn - 1 */
+        while (n < lim) {
             glz_u32x4 a[GLZ_ROWS], b[GLZ_ROWS];
             int k[GLZ_ROWS];
 #pragma unroll
             for (int u = 0; u < GLZ_ROWS; u++) {
                 k[u] = n + u * 256 + lane * 4;
-                const int kk = k[u] < maxn ? k[u] : maxn - 1;
+                const int kk = k[u] < lim ? k[u] : lim - 1;
                 a[u] = *(const GLZ_GLOBAL glz_u32x4_u *)(sbase + (size_t)(sidx + kk) * 4);
                 b[u] = *(const GLZ_GLOBAL glz_u32x4_u *)(rbase + (size_t)(ridx + kk) * 4);
             }
@@ -312,7 +313,7 @@ __device__ __forceinline__ int glz_match_len(const GLZ_GLOBAL uint8_t *sbase, in
             uint64_t stop[GLZ_ROWS];
 #pragma unroll
             for (int u = 0; u < GLZ_ROWS; u++) {
-                int valid = maxn - k[u];
+                int valid = lim - k[u];
                 valid = valid < 0 ? 0 : (valid > 4 ? 4 : valid);
                 const int g = glz_agree4(a[u], b[u], mask);
                 sub[u] = g < valid ? g : valid;
@@ -334,6 +335,16 @@ __device__ __forceinline__ int glz_match_len(const GLZ_GLOBAL uint8_t *sbase, in
             if (done) {
                 break;
             }
+        }
+        if (n >= lim) {
+            /* the last three pixels one by one */
+            n = lim > start ? lim : start;
+            const int k = n + lane;
+            bool differ = true;
+            if (k < maxn) {
+                differ = ((glz_load_px<MODE>(sbase, sidx + k) ^ glz_load_px<MODE>(rbase, ridx + k)) & T::MASK) != 0;
+            }
+            n += __ffsll((unsigned long long)__ballot(differ)) - 1;
         }
     } else {
         while (n < maxn) {
@@ -384,20 +395,21 @@ __device__ __forceinline__ int glz_run_len(const GLZ_GLOBAL uint8_t *sbase, int 
         const uint32_t xr = MODE == GLZ_MODE_ALPHA ? (x & 0xffu) << 24 : x;
         glz_u32x4 xs;
         xs[0] = xs[1] = xs[2] = xs[3] = xr;
-        while (n < maxn) {
+        const int lim = maxn - 3; /* a group of four never reaches past maxn - 1 */
+        while (n < lim) {
             glz_u32x4 a[GLZ_ROWS];
             int k[GLZ_ROWS];
 #pragma unroll
             for (int u = 0; u < GLZ_ROWS; u++) {
                 k[u] = n + u * 256 + lane * 4;
-                const int kk = k[u] < maxn ? k[u] : maxn - 1;
+                const int kk = k[u] < lim ? k[u] : lim - 1;
                 a[u] = *(const GLZ_GLOBAL glz_u32x4_u *)(sbase + (size_t)(sidx + kk) * 4);
             }
             int sub[GLZ_ROWS];
             uint64_t stop[GLZ_ROWS];
 #pragma unroll
             for (int u = 0; u < GLZ_ROWS; u++) {
-                int valid = maxn - k[u];
+                int valid = lim - k[u];
                 valid = valid < 0 ? 0 : (valid > 4 ? 4 : valid);
                 const int g = glz_agree4(a[u], xs, mask);
                 sub[u] = g < valid ? g : valid;
@@ -419,6 +431,16 @@ __device__ __forceinline__ int glz_run_len(const GLZ_GLOBAL uint8_t *sbase, int 
             if (done) {
                 break;
             }
+        }
+        if (n >= lim) {
+            /* the last three pixels one by one */
+            n = lim > 0 ? lim : 0;
+            const int k = n + lane;
+            bool differ = true;
+            if (k < maxn) {
+                differ = ((glz_load_px<MODE>(sbase, sidx + k) ^ x) & T::MASK) != 0;
+            }
+            n += __ffsll((unsigned long long)__ballot(differ)) - 1;
         }
     } else {
         while (n < maxn) {
@@ -499,6 +521,17 @@ __shared__ GlzShared glz_sh;
 __device__ __forceinline__ const GLZ_GLOBAL uint8_t *glz_arena(const GlzDevJob &job)
 {
     return (const GLZ_GLOBAL uint8_t *)(uintptr_t)job.arena;
+}
+
+/* Where a segment's pixels are.  A single-segment image of a device-resident
+ * batch is parsed straight from the caller's buffer while its copy into the
+ * window arena (needed by later images only) runs beside the parse. */
+__device__ __forceinline__ const GLZ_GLOBAL uint8_t *glz_seg_base(const GlzDevJob &job, uint32_t seg_idx,
+                                                                  const GlzDevSeg &s)
+{
+    const GLZ_GLOBAL uint8_t *in_arena = glz_arena(job) + (size_t)s.arena_off16 * 16;
+    const GLZ_GLOBAL uint8_t *own = (const GLZ_GLOBAL uint8_t *)(uintptr_t)job.own_src;
+    return (job.own_src != nullptr && seg_idx == job.own_seg) ? own : in_arena;
 }
 
 __device__ __forceinline__ GLZ_GLOBAL uint8_t *glz_out(const GlzDevJob &job)
@@ -760,7 +793,7 @@ __device__ __forceinline__ void glz_window_scan(const GlzDevJob &job, const GlzD
                 pdist = (uint64_t)he.y + rs.img_first_delta;
             }
             if (pdist != 0 && pdist < 33554432ull && idist <= 16777215ull) {
-                const GLZ_GLOBAL uint8_t *rbase = glz_arena(job) + (size_t)rs.arena_off16 * 16;
+                const GLZ_GLOBAL uint8_t *rbase = glz_seg_base(job, he.x, rs);
                 const int ref = (int)he.y;
                 const int rmax = (int)rs.nunits - ref;
                 maxk = rmax < maxn ? rmax : maxn;
@@ -1148,8 +1181,9 @@ __device__ __forceinline__ int glz_resolve_general(const GlzDevJob &job, const G
             maxed = a & GLZ_A_GMAX;
             sel = GLZ_SEL_TABLE;
             if (maxed) {
-                const GlzDevSeg rs = glz_seg(job, sh, glz_uniform(sh.g_seg[i]));
-                const GLZ_GLOBAL uint8_t *rbase = glz_arena(job) + (size_t)rs.arena_off16 * 16;
+                const uint32_t rseg = glz_uniform(sh.g_seg[i]);
+                const GlzDevSeg rs = glz_seg(job, sh, rseg);
+                const GLZ_GLOBAL uint8_t *rbase = glz_seg_base(job, rseg, rs);
                 const int ref = (int)glz_uniform(sh.g_ref[i]);
                 int maxn = ip_bound - anchor;
                 const int rmax = (int)rs.nunits - ref;
@@ -1500,7 +1534,7 @@ __device__ __forceinline__ void glz_parse_seg(const GlzDevJob &job, uint32_t seg
     const int lane = tid & 63;
     const bool w0 = tid < GLZ_WAVE;
     const GlzDevSeg cs = glz_seg(job, sh, seg_idx);
-    const GLZ_GLOBAL uint8_t *base = glz_arena(job) + (size_t)cs.arena_off16 * 16;
+    const GLZ_GLOBAL uint8_t *base = glz_seg_base(job, seg_idx, cs);
     const int npix = (int)cs.nunits;
     const int ip_limit = npix - 6;
     int ip = from;
@@ -1547,7 +1581,7 @@ __device__ __forceinline__ void glz_parse_image(const GlzDevJob &job, const uint
             break;
         }
         if (cs.nunits > 0 && w0) {
-            const GLZ_GLOBAL uint8_t *base = glz_arena(job) + (size_t)cs.arena_off16 * 16;
+            const GLZ_GLOBAL uint8_t *base = glz_seg_base(job, seg_list[s], cs);
             glz_run_from_arena<MODE>(job, base, 0, (int)cs.nunits, true, lane);
         }
         __syncthreads();
@@ -1559,7 +1593,7 @@ __device__ __forceinline__ void glz_parse_image(const GlzDevJob &job, const uint
             /* the first real segment starts with a hash insert and two literals */
             if (w0) {
                 const GlzDevSeg cs = glz_seg(job, sh, sid);
-                const GLZ_GLOBAL uint8_t *base = glz_arena(job) + (size_t)cs.arena_off16 * 16;
+                const GLZ_GLOBAL uint8_t *base = glz_seg_base(job, sid, cs);
                 if (lane == 0) {
                     glz_htab_store(job, glz_hash_at<MODE>(base, 0), sid, 0);
                 }

@@ -18,7 +18,8 @@ std::mutex g_device_mutex;
 std::mutex g_stat_mutex;
 bool g_ready = false;
 int g_device = -1;
-hipStream_t g_stream = nullptr;
+hipStream_t g_stream = nullptr, g_side_stream = nullptr;
+hipEvent_t g_fork = nullptr, g_join = nullptr;
 thread_local char g_error[512] = "";
 SpiceGpuCodecStats g_stats[SPICE_GPU_STAT_COUNT];
 } // namespace
@@ -58,6 +59,12 @@ static bool init_locked(int device)
                             "hipStreamCreate")) {
         return false;
     }
+    if (!g_side_stream && !(check(hipStreamCreateWithFlags(&g_side_stream, hipStreamNonBlocking),
+                                  "hipStreamCreate") &&
+                            check(hipEventCreate(&g_fork), "hipEventCreate") &&
+                            check(hipEventCreate(&g_join), "hipEventCreate"))) {
+        return false;
+    }
     g_device = device;
     g_ready = true;
     return true;
@@ -76,6 +83,21 @@ bool ensure_init()
 hipStream_t stream()
 {
     return g_stream;
+}
+
+hipStream_t side_stream()
+{
+    return g_side_stream;
+}
+
+hipEvent_t fork_event()
+{
+    return g_fork;
+}
+
+hipEvent_t join_event()
+{
+    return g_join;
 }
 
 std::mutex &device_mutex()

@@ -20,6 +20,10 @@ namespace spicegpu {
  * Returns false, with the error text set, when no GPU can be used. */
 bool ensure_init();
 hipStream_t stream();
+/* a second stream for work that may run beside stream()'s, and two events to order them */
+hipStream_t side_stream();
+hipEvent_t fork_event();
+hipEvent_t join_event();
 void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
 bool check(hipError_t e, const char *what);
 

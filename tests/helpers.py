@@ -43,8 +43,10 @@ def assert_same_stream(expected, got, what=""):
 class GlzPair:
     """One oracle dictionary and one device dictionary fed the same images."""
 
-    def __init__(self, gpu, oracle, size_px, max_encoders=1):
-        self.gpu, self.O = gpu, oracle
+    def __init__(self, gpu, oracle, size_px, max_encoders=1, batch=False):
+        """batch=True sends the images through the device-resident batch interface
+        (pixels uploaded first, stream downloaded) instead of glz_encode"""
+        self.gpu, self.O, self.batch = gpu, oracle, batch
         self.od = oracle.GlzDict(size_px, max_encoders)
         self.gd = B.GlzDictionary(gpu, size_px, max_encoders)
         self.ge = B.GlzEncoder(gpu, self.gd, 0)
@@ -54,8 +56,24 @@ class GlzPair:
         tag = 1000 + self.n
         self.n += 1
         so, oimg = self.od.encode(typ, w, h, stride, chunks, top_down=top_down, usr_tag=tag)
-        sg, gimg = self.ge.encode(typ, w, h, stride, chunks, top_down=top_down, usr_context=tag,
-                                  first_lines_direct=direct)
+        if self.batch:
+            dev = self.gpu
+            held = [dev.to_device(c) for c in chunks]
+            cap = dev.L.spice_gpu_glz_out_bound(typ, w, h)
+            out = dev.malloc(cap)
+            try:
+                sizes, imgs = B.glz_encode_batch(dev, [dict(
+                    encoder=self.ge, type=typ, width=w, height=h, stride=stride, top_down=top_down,
+                    chunks=held, chunk_rows=[c.shape[0] for c in chunks], out=out, out_capacity=cap,
+                    usr_context=tag)])
+                sg, gimg = dev.download(out, sizes[0]), imgs[0]
+            finally:
+                dev.free(out)
+                for p in held:
+                    dev.free(p)
+        else:
+            sg, gimg = self.ge.encode(typ, w, h, stride, chunks, top_down=top_down, usr_context=tag,
+                                      first_lines_direct=direct)
         assert_same_stream(so, sg, "%s image %d (%dx%d type %d)" % (what, self.n - 1, w, h, typ))
         assert self.od.pop_freed() == self.gd.usr.freed_images
         self.gd.usr.freed_images.clear()

@@ -109,6 +109,7 @@ const char *hipGetErrorString(hipError_t e);
 hipError_t hipEventCreate(hipEvent_t *e);
 hipError_t hipEventDestroy(hipEvent_t e);
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s = 0);
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags = 0);
 hipError_t hipEventSynchronize(hipEvent_t e);
 hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b);
 template <class T>

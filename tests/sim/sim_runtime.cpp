@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
+#include <execinfo.h>
+#include <signal.h>
 #include <sys/mman.h>
 #include <time.h>
 #include <unistd.h>
@@ -173,8 +175,42 @@ uint64_t sim_exchange64(uint64_t v, int, int mode, int arg)
     return r;
 }
 
+/* A fault inside a kernel (typically a read past a guarded buffer) names the
+ * work-item and the call chain before the process dies. */
+static void sim_on_segv(int, siginfo_t *si, void *)
+{
+    fprintf(stderr, "sim: fault at address %p in work-item %d of block (%u,%u,%u)\n", si->si_addr,
+            cur_fiber, blockIdx.x, blockIdx.y, blockIdx.z);
+    void *frames[24];
+    int n = backtrace(frames, 24);
+    for (int i = 0; i < n; i++) {
+        Dl_info di;
+        memset(&di, 0, sizeof(di));
+        dladdr(frames[i], &di);
+        fprintf(stderr, "sim:   +0x%lx %s (%s)\n", (unsigned long)((char *)frames[i] - (char *)di.dli_fbase),
+                di.dli_sname ? di.dli_sname : "?", di.dli_fname ? di.dli_fname : "?");
+    }
+    signal(SIGSEGV, SIG_DFL);
+    raise(SIGSEGV);
+}
+
 void sim_run_grid(dim3 grid, dim3 block, const std::function<void()> &body)
 {
+    static bool handler_installed = false;
+    if (!handler_installed) {
+        static char alt_stack[64 * 1024];
+        stack_t ss;
+        ss.ss_sp = alt_stack;
+        ss.ss_size = sizeof(alt_stack);
+        ss.ss_flags = 0;
+        sigaltstack(&ss, NULL);
+        struct sigaction sa;
+        memset(&sa, 0, sizeof(sa));
+        sa.sa_sigaction = sim_on_segv;
+        sa.sa_flags = SA_SIGINFO | SA_ONSTACK;
+        sigaction(SIGSEGV, &sa, NULL);
+        handler_installed = true;
+    }
     int threads = (int)(block.x * block.y * block.z);
     if (threads <= 0 || threads > kMaxThreads) {
         fprintf(stderr, "sim: bad block size %d\n", threads);
@@ -367,6 +403,7 @@ hipError_t hipEventRecord(hipEvent_t e, hipStream_t)
     return hipSuccess;
 }
 hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; } /* launches are synchronous here */
 hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b)
 {
     *ms = (float)(b->t - a->t);

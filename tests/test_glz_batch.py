@@ -29,6 +29,8 @@ class Session:
         if self.kind == "noise":
             im = np.zeros((self.h, self.w, 4), np.uint8)
             im[..., :3] = self.rng.integers(0, 256, (self.h, self.w, 3))
+        elif self.kind == "repeat":       # the same picture every time: one match to the segment's end
+            im = frames.DesktopSequence(max(self.w, 96), max(self.h, 96), 77).next()[:self.h, :self.w].copy()
         elif self.kind == "flat":
             im = np.zeros((self.h, self.w, 4), np.uint8)
             im[..., :3] = self.rng.integers(0, 256, 3)
@@ -73,7 +75,9 @@ def run_batches(dev, oracle, specs, nframes, window):
 SMALL = [(B.LZ_IMAGE_TYPE_RGB32, 96, 40, "desktop"), (B.LZ_IMAGE_TYPE_RGB32, 64, 64, "noise"),
          (B.LZ_IMAGE_TYPE_RGBA, 80, 30, "desktop"), (B.LZ_IMAGE_TYPE_RGB16, 120, 20, "flat"),
          (B.LZ_IMAGE_TYPE_RGB24, 33, 17, "desktop"), (B.LZ_IMAGE_TYPE_RGB32, 7, 3, "noise"),
-         (B.LZ_IMAGE_TYPE_RGB32, 200, 30, "flat")]
+         (B.LZ_IMAGE_TYPE_RGB32, 200, 30, "flat"), (B.LZ_IMAGE_TYPE_RGB32, 131, 37, "repeat"),
+         (B.LZ_IMAGE_TYPE_RGBA, 64, 33, "repeat"), (B.LZ_IMAGE_TYPE_RGB24, 50, 21, "repeat"),
+         (B.LZ_IMAGE_TYPE_RGB32, 129, 1, "flat"), (B.LZ_IMAGE_TYPE_RGB32, 258, 3, "flat")]
 
 
 def test_sim_batch_of_mixed_sessions(sim, oracle):

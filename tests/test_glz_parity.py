@@ -17,11 +17,11 @@ TYPES = [B.LZ_IMAGE_TYPE_RGB32, B.LZ_IMAGE_TYPE_RGBA, B.LZ_IMAGE_TYPE_RGB24, B.L
 SIZES = [(64, 32), (100, 60), (7, 3), (1, 1), (3, 1), (200, 50), (2, 2), (130, 70), (6, 1), (7, 1)]
 
 
-def run_mixed_sequence(dev, oracle, typ, nimages, window=40000):
+def run_mixed_sequence(dev, oracle, typ, nimages, window=40000, batch=False):
     """Small window so that images are evicted; ragged sizes; 1..3 chunks;
     one logical removal; both row orders."""
     rng = np.random.default_rng(typ)
-    pair = GlzPair(dev, oracle, window)
+    pair = GlzPair(dev, oracle, window, batch=batch)
     try:
         for i in range(nimages):
             w, h = SIZES[i % len(SIZES)]
@@ -36,11 +36,11 @@ def run_mixed_sequence(dev, oracle, typ, nimages, window=40000):
         pair.close()
 
 
-def run_noise_and_runs(dev, oracle, typ):
+def run_noise_and_runs(dev, oracle, typ, batch=False):
     """Incompressible noise (all literals), a constant image (one run), stripes
     with period inside and outside the 64-position window."""
     rng = np.random.default_rng(99)
-    pair = GlzPair(dev, oracle, 1 << 16)
+    pair = GlzPair(dev, oracle, 1 << 16, batch=batch)
     try:
         w, h = 96, 40
         imgs = []
@@ -90,13 +90,13 @@ def run_plumbing(dev, oracle):
         pair.close()
 
 
-def run_low_entropy(dev, oracle, typ, nimages, w, h):
+def run_low_entropy(dev, oracle, typ, nimages, w, h, batch=False):
     """Few colours in short random runs: nearly every 3-pixel hash recurs many
     times inside a 256-position window, so table slots are overwritten by
     stops, by match tails and -- for skipped positions -- not at all; runs of
     every length from 3 pixels to several windows."""
     rng = np.random.default_rng(1000 + typ)
-    pair = GlzPair(dev, oracle, w * h * 3)
+    pair = GlzPair(dev, oracle, w * h * 3, batch=batch)
     try:
         for i in range(nimages):
             ncol = 2 + i % 4
@@ -130,6 +130,17 @@ def test_sim_low_entropy(sim, oracle, typ):
     run_low_entropy(sim, oracle, typ, 10, 173, 29)
 
 
+@pytest.mark.parametrize("typ", TYPES)
+def test_sim_batch_interface_same_cases(sim, oracle, typ):
+    """the same images through spice_gpu_glz_encode_batch: single-chunk images are
+    parsed straight from the uploaded buffer (which the simulator ends at a guard
+    page), the others from the window arena"""
+    run_mixed_sequence(sim, oracle, typ, 40, batch=True)
+    run_low_entropy(sim, oracle, typ, 10, 173, 29, batch=True)
+    if typ != B.LZ_IMAGE_TYPE_RGB24:
+        run_noise_and_runs(sim, oracle, typ, batch=True)
+
+
 def test_sim_desktop_frames(sim, oracle):
     run_desktop_frames(sim, oracle, 320, 200, 4, window=200000, nchunks=2)
 
@@ -139,6 +150,13 @@ def test_sim_plumbing(sim, oracle):
 
 
 # ------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("typ", TYPES)
+def test_gpu_batch_interface_same_cases(gpu, oracle, typ):
+    run_mixed_sequence(gpu, oracle, typ, 60, batch=True)
+    run_low_entropy(gpu, oracle, typ, 15, 1031, 67, batch=True)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("typ", TYPES)
 def test_gpu_mixed_sequence(gpu, oracle, typ):
