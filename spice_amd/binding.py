@@ -776,3 +776,84 @@ def choose_codec(gpu, comp, fmt, x, y, stride, unstable, can_lossy, enable_jpeg,
                            graduality, glz_dict_size, int(glz_frozen))
     gpu.L.spice_gpu_choose_codec.restype = C.c_int
     return gpu.L.spice_gpu_choose_codec(C.byref(q))
+
+
+class ImageCompressor:
+    """red_compress_image for one display channel client (server/red_worker.c:6411-6525):
+    the choice of codec, then red_glz_compress_image (:6003-6102, with the optional
+    zlib wrap) or red_jpeg_compress_image (:6182-6279).  QUIC, LZ and the LZ-coded
+    alpha plane of JPEG_ALPHA belong to spice-common, which this library does not
+    replace: for those the result names the codec and carries no data.
+
+    compress() returns None where the reference returns FALSE (the bitmap goes out
+    raw), else a dict with "type" (the SPICE_IMAGE_TYPE_* name), "data" and, for
+    ZLIB_GLZ_RGB, "glz_data_size"."""
+
+    MIN_GLZ_SIZE_FOR_ZLIB = 100             # server/red_worker.c:133
+    FMT_TO_LZ = {BITMAP_FMT_16BIT: LZ_IMAGE_TYPE_RGB16, BITMAP_FMT_24BIT: LZ_IMAGE_TYPE_RGB24,
+                 BITMAP_FMT_32BIT: LZ_IMAGE_TYPE_RGB32, BITMAP_FMT_RGBA: LZ_IMAGE_TYPE_RGBA}
+    FMT_TO_JPEG = {BITMAP_FMT_16BIT: JPEG_IMAGE_TYPE_RGB16, BITMAP_FMT_24BIT: JPEG_IMAGE_TYPE_BGR24,
+                   BITMAP_FMT_32BIT: JPEG_IMAGE_TYPE_BGRX32, BITMAP_FMT_RGBA: JPEG_IMAGE_TYPE_BGRX32}
+
+    def __init__(self, gpu, image_compression, glz_window_px, enable_jpeg=True, jpeg_quality=85,
+                 enable_zlib_glz_wrap=False, zlib_level=3):
+        self.gpu = gpu
+        self.image_compression = image_compression
+        self.enable_jpeg, self.jpeg_quality = enable_jpeg, jpeg_quality     # :10623-10624
+        self.enable_zlib_glz_wrap, self.zlib_level = enable_zlib_glz_wrap, zlib_level
+        self.dict = GlzDictionary(gpu, glz_window_px, 1)
+        self.glz = GlzEncoder(gpu, self.dict, 0)
+        self.jpeg = JpegEncoder(gpu)
+        self.migrate_freeze = False
+        self._zlib, self._zlib_level_in_use = None, None
+
+    def close(self):
+        self.jpeg.close()
+        self.glz.close()
+        self.dict.close()
+
+    def _zlib_encode(self, data):
+        """zlib_encode (server/zlib_encoder.c:68-125): one deflate stream per image from a
+        z_stream that is reset, not re-created; input arrives in 64 KiB RedCompressBufs"""
+        import zlib
+        # deflateReset keeps the level; Python has no reset, a fresh object is the same stream
+        z = zlib.compressobj(self.zlib_level)
+        out = [z.compress(bytes(data[o:o + RED_COMPRESS_BUF_SIZE]))
+               for o in range(0, len(data), RED_COMPRESS_BUF_SIZE)]
+        out.append(z.flush())
+        return np.frombuffer(b"".join(out), dtype=np.uint8)
+
+    def compress(self, fmt, x, y, stride, chunks, top_down=True, unstable=False, can_lossy=False,
+                 drawable_graduality=BITMAP_GRADUAL_INVALID, usr_context=0):
+        query = lambda grad: choose_codec(self.gpu, self.image_compression, fmt, x, y, stride, unstable,
+                                          can_lossy, self.enable_jpeg, grad, self.dict.get_size(),
+                                          self.migrate_freeze)
+        codec = query(drawable_graduality)
+        if codec == CODEC_NEEDS_GRADUALITY:          # :6451-6455
+            codec = query(bitmap_graduality_level(self.gpu, fmt, x, chunks))
+        if codec == CODEC_NONE:
+            return None
+        if codec == CODEC_ERROR:
+            raise SpiceGpuError("invalid image compression type %r" % (self.image_compression,))
+        if codec == CODEC_QUIC:
+            return {"type": "QUIC", "data": None}
+        if codec == CODEC_LZ:
+            return {"type": "LZ_RGB", "data": None}
+        if codec == CODEC_JPEG:
+            if fmt not in self.FMT_TO_JPEG:
+                return None                          # :6218-6219
+            data = self.jpeg.encode(self.jpeg_quality, self.FMT_TO_JPEG[fmt], x, y, stride, chunks,
+                                    top_down=top_down)
+            if len(data) > y * stride:
+                return None                          # :6263-6266
+            if fmt == BITMAP_FMT_RGBA:
+                return {"type": "JPEG_ALPHA", "data": None, "jpeg": data}
+            return {"type": "JPEG", "data": data, "is_lossy": True}
+        data, image = self.glz.encode(self.FMT_TO_LZ[fmt], x, y, stride, chunks, top_down=top_down,
+                                      usr_context=usr_context)
+        if self.enable_zlib_glz_wrap and len(data) >= self.MIN_GLZ_SIZE_FOR_ZLIB:
+            wrapped = self._zlib_encode(data)
+            if len(wrapped) < len(data):             # :6075-6083
+                return {"type": "ZLIB_GLZ_RGB", "data": wrapped, "glz_data_size": len(data),
+                        "glz_image": image}
+        return {"type": "GLZ_RGB", "data": data, "glz_image": image}

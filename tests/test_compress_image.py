@@ -1,0 +1,118 @@
+"""red_compress_image as a whole (server/red_worker.c:6411-6525): for a stream of
+bitmaps of one client, the codec the library's policy picks and the bytes its
+encoders produce, against the same composition built from the oracle's parts
+(decision table, graduality, GLZ with its window history, libjpeg restatement)
+and zlib itself for the optional wrap (server/zlib_encoder.c calls the same
+library)."""
+import zlib
+
+import numpy as np
+import pytest
+
+from spice_amd import binding as B
+from spice_amd import frames
+
+from helpers import assert_same_stream, split_rows
+
+FMT_O = {B.BITMAP_FMT_16BIT: 6, B.BITMAP_FMT_24BIT: 7, B.BITMAP_FMT_32BIT: 8, B.BITMAP_FMT_RGBA: 9}
+
+
+def bitmaps(n):
+    """(format, pixels (h, stride), unstable, can_lossy): text-like, smooth and tiny ones"""
+    rng = np.random.default_rng(21)
+    seq = frames.DesktopSequence(160, 96, seed=4)
+    for k in range(n):
+        kind = k % 6
+        if kind in (0, 1, 4):
+            img = seq.next()[: 64 + 8 * (k % 3), : 120 + k % 7].copy()
+        elif kind == 2:
+            img = frames.golden_image(96 + k % 5, 80, "smooth", k)
+        elif kind == 3:
+            img = frames.golden_image(2, 40, "smooth", k)            # narrower than 3: never QUIC
+        else:
+            img = frames.golden_image(16, 1, "desktop", k)[:1, :13]    # 52 bytes: sent raw
+        h, w = img.shape[:2]
+        fmt = [B.BITMAP_FMT_32BIT, B.BITMAP_FMT_RGBA, B.BITMAP_FMT_24BIT, B.BITMAP_FMT_16BIT][(k // 2) % 4]
+        if fmt == B.BITMAP_FMT_24BIT:
+            px = frames.to_bgr24(img)
+        elif fmt == B.BITMAP_FMT_16BIT:
+            px = frames.to_rgb16(img, rng)
+        else:
+            px = img.reshape(h, w * 4).copy()
+            if fmt == B.BITMAP_FMT_RGBA:
+                px[:, 3::4] = 255
+        yield fmt, w, h, np.ascontiguousarray(px), k % 11 == 7, k % 3 != 0
+
+
+def run_stream(dev, oracle, comp_mode, zlib_wrap, n=36):
+    ic = B.ImageCompressor(dev, comp_mode, glz_window_px=60000, enable_zlib_glz_wrap=zlib_wrap)
+    od = oracle.GlzDict(60000, 1)
+    seen = {}
+    try:
+        for k, (fmt, w, h, px, unstable, can_lossy) in enumerate(bitmaps(n)):
+            stride = px.shape[1]
+            chunks = split_rows(px, 1 + k % 3)
+            top_down = k % 4 != 3
+            got = ic.compress(fmt, w, h, stride, chunks, top_down=top_down, unstable=unstable,
+                              can_lossy=can_lossy, usr_context=100 + k)
+            # ---- what the reference's composition yields
+            codec = oracle.choose_codec(comp_mode, FMT_O[fmt], w, h, stride, unstable, can_lossy, True,
+                                        B.BITMAP_GRADUAL_INVALID, 60000, False)
+            if codec == B.CODEC_NEEDS_GRADUALITY:
+                level = oracle.graduality(FMT_O[fmt], w, chunks)[0]
+                codec = oracle.choose_codec(comp_mode, FMT_O[fmt], w, h, stride, unstable, can_lossy, True,
+                                            level, 60000, False)
+            what = "bitmap %d fmt %d %dx%d codec %d" % (k, fmt, w, h, codec)
+            if codec == B.CODEC_NONE:
+                assert got is None, what
+                seen["raw"] = seen.get("raw", 0) + 1
+            elif codec == B.CODEC_QUIC:
+                assert got == {"type": "QUIC", "data": None}, what
+            elif codec == B.CODEC_LZ:
+                assert got == {"type": "LZ_RGB", "data": None}, what
+            elif codec == B.CODEC_JPEG:
+                rows = px if top_down else np.ascontiguousarray(px[::-1])
+                want = oracle.jpeg_encode(rows, w, h, stride, FMT_O[fmt], 85, oracle.DCT_ISLOW)
+                if len(want) > h * stride:
+                    assert got is None, what
+                elif fmt == B.BITMAP_FMT_RGBA:
+                    assert got["type"] == "JPEG_ALPHA" and got["data"] is None, what
+                    assert_same_stream(want, got["jpeg"], what)
+                else:
+                    assert got["type"] == "JPEG" and got["is_lossy"], what
+                    assert_same_stream(want, got["data"], what)
+            else:
+                assert codec == B.CODEC_GLZ
+                want, _ = od.encode(FMT_O[fmt], w, h, stride, chunks, top_down=top_down, usr_tag=100 + k)
+                if zlib_wrap and len(want) >= 100 and len(zlib.compress(bytes(want), 3)) < len(want):
+                    assert got["type"] == "ZLIB_GLZ_RGB" and got["glz_data_size"] == len(want), what
+                    assert bytes(got["data"]) == zlib.compress(bytes(want), 3), what
+                    assert zlib.decompress(bytes(got["data"])) == bytes(want)
+                else:
+                    assert got["type"] == "GLZ_RGB", what
+                    assert_same_stream(want, got["data"], what)
+            if got is not None:
+                seen[got["type"]] = seen.get(got["type"], 0) + 1
+    finally:
+        ic.close()
+        od.close()
+    return seen
+
+
+def test_sim_auto_glz_with_zlib_wrap(sim, oracle):
+    seen = run_stream(sim, oracle, B.IMAGE_COMPRESS_AUTO_GLZ, True)
+    assert seen.get("ZLIB_GLZ_RGB", 0) >= 3 and seen.get("raw", 0) >= 1
+    assert seen.get("JPEG", 0) + seen.get("JPEG_ALPHA", 0) + seen.get("QUIC", 0) >= 2
+
+
+def test_sim_other_modes(sim, oracle):
+    assert run_stream(sim, oracle, B.IMAGE_COMPRESS_GLZ, False, 18).get("GLZ_RGB", 0) >= 8
+    assert run_stream(sim, oracle, B.IMAGE_COMPRESS_AUTO_LZ, False, 12).get("LZ_RGB", 0) >= 3
+    assert run_stream(sim, oracle, B.IMAGE_COMPRESS_QUIC, False, 12).get("QUIC", 0) >= 6
+    assert run_stream(sim, oracle, B.IMAGE_COMPRESS_OFF, False, 6) == {"raw": 6}
+
+
+@pytest.mark.gpu
+def test_gpu_auto_glz_with_zlib_wrap(gpu, oracle):
+    seen = run_stream(gpu, oracle, B.IMAGE_COMPRESS_AUTO_GLZ, True, 48)
+    assert seen.get("ZLIB_GLZ_RGB", 0) >= 3 and seen.get("GLZ_RGB", 0) + seen.get("ZLIB_GLZ_RGB", 0) >= 12
