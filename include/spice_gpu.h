@@ -305,11 +305,16 @@ typedef struct SpiceGpuGlzJob {
 /* Bytes the output buffer of a job must hold in the worst case. */
 size_t spice_gpu_glz_out_bound(LzImageType type, int width, int height);
 
-/* Encodes njobs images, at most one per dictionary, in one pass: a copy of
- * the rows into each dictionary's HBM window, then one parse launch with one
- * wavefront per job.  Jobs of different dictionaries run concurrently; the
- * call returns when all results are back.  Returns 0, or -1 with
- * spice_gpu_last_error set (job fields say which job failed). */
+/* Encodes njobs images, at most one per dictionary, in one pass: one parse
+ * launch with a 256-lane workgroup per job, and a copy of the rows into each
+ * dictionary's window in device memory.  An image of one chunk is parsed where
+ * the caller put it and its copy runs beside the parse; other images are copied
+ * first.  The chunk buffers must stay valid and unchanged until the call (or
+ * spice_gpu_glz_finish) returns.  Workgroups start in the order of expected
+ * cost (image size x how the dictionary's previous image compressed), so a
+ * batch may hold more jobs than the device runs at once; results come back in
+ * the caller's job order.  Returns 0, or -1 with spice_gpu_last_error set (job
+ * fields say which job failed). */
 int spice_gpu_glz_encode_batch(SpiceGpuGlzJob *jobs, int njobs);
 
 /* As above but split in two so that callers can time the device work alone
