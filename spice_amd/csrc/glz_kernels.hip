@@ -76,8 +76,10 @@
  * global loads and values read at a wave-uniform address stay wave-uniform. */
 #ifdef SPICE_WAVE_SIM
 #define GLZ_GLOBAL
+#define GLZ_SIX_PER_CU
 #else
 #define GLZ_GLOBAL __attribute__((address_space(1)))
+#define GLZ_SIX_PER_CU __attribute__((amdgpu_waves_per_eu(6, 6))) /* 80 VGPRs */
 #endif
 typedef uint32_t glz_u32x4 __attribute__((vector_size(16)));
 typedef glz_u32x4 glz_u32x4_u __attribute__((aligned(4))); /* pixel-aligned only */
@@ -1612,7 +1614,7 @@ template <int TYPE>
 /* Six workgroups per CU (80 VGPRs, a few spilled dwords): a session's parse is
  * bound by its own latency chain, so the GPU's throughput is the number of
  * sessions it holds at once. */
-__global__ void __launch_bounds__(GLZ_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6)))
+__global__ void __launch_bounds__(GLZ_THREADS) GLZ_SIX_PER_CU
 glz_parse_kernel(const GlzDevJob *__restrict__ jobs, const uint32_t *__restrict__ u32_pool,
                  const GlzDevSegUpdate *__restrict__ upd_pool)
 {
