@@ -44,55 +44,66 @@ def bitmaps(n):
         yield fmt, w, h, np.ascontiguousarray(px), k % 11 == 7, k % 3 != 0
 
 
+def expected(oracle, od, comp_mode, zlib_wrap, k, fmt, w, h, px, chunks, top_down, unstable, can_lossy):
+    """what the reference's composition yields for one bitmap: None (sent raw) or
+    (type name, bytes or None, glz_data_size)"""
+    stride = px.shape[1]
+    codec = oracle.choose_codec(comp_mode, FMT_O[fmt], w, h, stride, unstable, can_lossy, True,
+                                B.BITMAP_GRADUAL_INVALID, 60000, False)
+    if codec == B.CODEC_NEEDS_GRADUALITY:
+        level = oracle.graduality(FMT_O[fmt], w, chunks)[0]
+        codec = oracle.choose_codec(comp_mode, FMT_O[fmt], w, h, stride, unstable, can_lossy, True,
+                                    level, 60000, False)
+    if codec == B.CODEC_NONE:
+        return None
+    if codec == B.CODEC_QUIC:
+        return "QUIC", None, 0
+    if codec == B.CODEC_LZ:
+        return "LZ_RGB", None, 0
+    if codec == B.CODEC_JPEG:
+        rows = px if top_down else np.ascontiguousarray(px[::-1])
+        want = oracle.jpeg_encode(rows, w, h, stride, FMT_O[fmt], 85, oracle.DCT_ISLOW)
+        if len(want) > h * stride:
+            return None
+        return ("JPEG_ALPHA" if fmt == B.BITMAP_FMT_RGBA else "JPEG"), want, 0
+    assert codec == B.CODEC_GLZ
+    want, _ = od.encode(FMT_O[fmt], w, h, stride, chunks, top_down=top_down, usr_tag=100 + k)
+    if zlib_wrap and len(want) >= 100:
+        wrapped = zlib.compress(bytes(want), 3)
+        if len(wrapped) < len(want):
+            assert zlib.decompress(wrapped) == bytes(want)
+            return "ZLIB_GLZ_RGB", np.frombuffer(wrapped, dtype=np.uint8), len(want)
+    return "GLZ_RGB", want, 0
+
+
 def run_stream(dev, oracle, comp_mode, zlib_wrap, n=36):
     ic = B.ImageCompressor(dev, comp_mode, glz_window_px=60000, enable_zlib_glz_wrap=zlib_wrap)
     od = oracle.GlzDict(60000, 1)
     seen = {}
     try:
         for k, (fmt, w, h, px, unstable, can_lossy) in enumerate(bitmaps(n)):
-            stride = px.shape[1]
             chunks = split_rows(px, 1 + k % 3)
             top_down = k % 4 != 3
-            got = ic.compress(fmt, w, h, stride, chunks, top_down=top_down, unstable=unstable,
+            got = ic.compress(fmt, w, h, px.shape[1], chunks, top_down=top_down, unstable=unstable,
                               can_lossy=can_lossy, usr_context=100 + k)
-            # ---- what the reference's composition yields
-            codec = oracle.choose_codec(comp_mode, FMT_O[fmt], w, h, stride, unstable, can_lossy, True,
-                                        B.BITMAP_GRADUAL_INVALID, 60000, False)
-            if codec == B.CODEC_NEEDS_GRADUALITY:
-                level = oracle.graduality(FMT_O[fmt], w, chunks)[0]
-                codec = oracle.choose_codec(comp_mode, FMT_O[fmt], w, h, stride, unstable, can_lossy, True,
-                                            level, 60000, False)
-            what = "bitmap %d fmt %d %dx%d codec %d" % (k, fmt, w, h, codec)
-            if codec == B.CODEC_NONE:
+            want = expected(oracle, od, comp_mode, zlib_wrap, k, fmt, w, h, px, chunks, top_down,
+                            unstable, can_lossy)
+            what = "bitmap %d fmt %d %dx%d -> %s" % (k, fmt, w, h, want and want[0])
+            if want is None:
                 assert got is None, what
                 seen["raw"] = seen.get("raw", 0) + 1
-            elif codec == B.CODEC_QUIC:
-                assert got == {"type": "QUIC", "data": None}, what
-            elif codec == B.CODEC_LZ:
-                assert got == {"type": "LZ_RGB", "data": None}, what
-            elif codec == B.CODEC_JPEG:
-                rows = px if top_down else np.ascontiguousarray(px[::-1])
-                want = oracle.jpeg_encode(rows, w, h, stride, FMT_O[fmt], 85, oracle.DCT_ISLOW)
-                if len(want) > h * stride:
-                    assert got is None, what
-                elif fmt == B.BITMAP_FMT_RGBA:
-                    assert got["type"] == "JPEG_ALPHA" and got["data"] is None, what
-                    assert_same_stream(want, got["jpeg"], what)
-                else:
-                    assert got["type"] == "JPEG" and got["is_lossy"], what
-                    assert_same_stream(want, got["data"], what)
+                continue
+            assert got is not None and got["type"] == want[0], what
+            seen[want[0]] = seen.get(want[0], 0) + 1
+            if want[0] == "JPEG_ALPHA":
+                assert got["data"] is None
+                assert_same_stream(want[1], got["jpeg"], what)
+            elif want[1] is None:
+                assert got["data"] is None, what
             else:
-                assert codec == B.CODEC_GLZ
-                want, _ = od.encode(FMT_O[fmt], w, h, stride, chunks, top_down=top_down, usr_tag=100 + k)
-                if zlib_wrap and len(want) >= 100 and len(zlib.compress(bytes(want), 3)) < len(want):
-                    assert got["type"] == "ZLIB_GLZ_RGB" and got["glz_data_size"] == len(want), what
-                    assert bytes(got["data"]) == zlib.compress(bytes(want), 3), what
-                    assert zlib.decompress(bytes(got["data"])) == bytes(want)
-                else:
-                    assert got["type"] == "GLZ_RGB", what
-                    assert_same_stream(want, got["data"], what)
-            if got is not None:
-                seen[got["type"]] = seen.get(got["type"], 0) + 1
+                assert_same_stream(want[1], got["data"], what)
+                if want[0] == "ZLIB_GLZ_RGB":
+                    assert got["glz_data_size"] == want[2], what
     finally:
         ic.close()
         od.close()
