@@ -531,32 +531,46 @@ __device__ void jpeg_strip_body(const JpegDevJob &job, const uint32_t *huff_g, i
             const int t = v < 0 ? -v : v, t2 = v + (v >> 31);
             const int nb = 32 - __clz(t);
             const uint32_t vbits = (uint32_t)t2 & ((1u << nb) - 1);
-            const uint64_t before = nz & ((1ull << lane) - 1);
-            const int run = lane - 1 - (before ? 63 - __clzll((long long)before) : 0);
-            const bool ac = v != 0 && lane != 0;
-            const int idx = lane == 0 ? dc_off + nb : ac_off + (ac ? ((run & 15) << 4) + nb : 0);
-            const uint32_t e = huff[idx];
-            const int es = (int)(e >> 16);
-            const uint32_t code = ((e & 0xffff) << nb) | vbits;
-            int len = (ac || lane == 0 || lane == 63) ? es + nb : 0;
-            /* runs of 16 zeros and more take ZRL codes first; rare */
-            const int nzrl = ac ? run >> 4 : 0;
-            const uint32_t z = bi < 4 ? zrl : zrl_c;
-            const bool any_zrl = __ballot(nzrl != 0) != 0;
-            if (any_zrl) {
-                len += nzrl * (int)(z >> 16);
-            }
-            const uint32_t inc = wave_scan_inclusive((uint32_t)len, lane);
-            const uint32_t total = wave_broadcast(inc, 63);
-            if (len) {
-                uint32_t pos = bits + inc - (uint32_t)len;
-                if (any_zrl) {
-                    for (int i = 0; i < nzrl; i++) {
-                        jpeg_ring_put(ring, pos, z & 0xffff, (int)(z >> 16));
-                        pos += z >> 16;
-                    }
+            uint32_t total;
+            if (nz == 0) {
+                /* no AC coefficient at all (about every other block of video content):
+                 * the DC code and the end-of-block code, both written by lane 0 */
+                const uint32_t e = huff[dc_off + nb];
+                const uint32_t eob = huff[ac_off];
+                const int el = (int)(eob >> 16);
+                const int len = (int)(e >> 16) + nb + el;
+                if (lane == 0) {
+                    jpeg_ring_put(ring, bits, ((((e & 0xffff) << nb) | vbits) << el) | (eob & 0xffff), len);
                 }
-                jpeg_ring_put(ring, pos, code, es + nb);
+                total = (uint32_t)__builtin_amdgcn_readfirstlane(len);
+            } else {
+                const uint64_t before = nz & ((1ull << lane) - 1);
+                const int run = lane - 1 - (before ? 63 - __clzll((long long)before) : 0);
+                const bool ac = v != 0 && lane != 0;
+                const int idx = lane == 0 ? dc_off + nb : ac_off + (ac ? ((run & 15) << 4) + nb : 0);
+                const uint32_t e = huff[idx];
+                const int es = (int)(e >> 16);
+                const uint32_t code = ((e & 0xffff) << nb) | vbits;
+                int len = (ac || lane == 0 || lane == 63) ? es + nb : 0;
+                /* runs of 16 zeros and more take ZRL codes first; rare */
+                const int nzrl = ac ? run >> 4 : 0;
+                const uint32_t z = bi < 4 ? zrl : zrl_c;
+                const bool any_zrl = __ballot(nzrl != 0) != 0;
+                if (any_zrl) {
+                    len += nzrl * (int)(z >> 16);
+                }
+                const uint32_t inc = wave_scan_inclusive((uint32_t)len, lane);
+                total = wave_broadcast(inc, 63);
+                if (len) {
+                    uint32_t pos = bits + inc - (uint32_t)len;
+                    if (any_zrl) {
+                        for (int i = 0; i < nzrl; i++) {
+                            jpeg_ring_put(ring, pos, z & 0xffff, (int)(z >> 16));
+                            pos += z >> 16;
+                        }
+                    }
+                    jpeg_ring_put(ring, pos, code, es + nb);
+                }
             }
             bits += total;
             __builtin_amdgcn_wave_barrier();
