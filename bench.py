@@ -244,7 +244,7 @@ class MjpegWorkload:
         from oracle import oracle as O
         threads = max(1, min(16, os.cpu_count() or 1))
         use_ref = O.ref() is not None
-        frames_per_thread = 3
+        frames_per_thread = 12   # about 20 s of CPU work in all
         px = [f.reshape(H2160, -1) for f in self.host_frames]
 
         def work(t):
