@@ -187,6 +187,16 @@ bool arena_regrow(Dict *d, uint64_t need)
         const uint64_t len = im->arena_end - im->arena_begin;
         ok = check(hipMemcpyAsync(fresh + pos, d->d_arena + im->arena_begin, len,
                                   hipMemcpyDeviceToDevice, st), "move window image");
+        pos += len;
+    }
+    ok = ok && check(hipStreamSynchronize(st), "sync");
+    if (!ok) {
+        hipFree(fresh); /* nothing of the dictionary has changed yet */
+        return false;
+    }
+    pos = 0;
+    for (HostImage *im = d->used_images_head; im; im = im->next) {
+        const uint64_t len = im->arena_end - im->arena_begin;
         for (uint32_t sid = im->first_seg; sid != kNullSeg && d->segs[sid].image == im;
              sid = d->segs[sid].next) {
             d->segs[sid].arena_off = d->segs[sid].arena_off - im->arena_begin + pos;
@@ -195,11 +205,6 @@ bool arena_regrow(Dict *d, uint64_t need)
         im->arena_begin = pos;
         im->arena_end = pos + len;
         pos += len;
-    }
-    ok = ok && check(hipStreamSynchronize(st), "sync");
-    if (!ok) {
-        hipFree(fresh); /* offsets are stale now: the dictionary must be reset by its owner */
-        return false;
     }
     hipFree(d->d_arena);
     d->d_arena = fresh;
