@@ -69,6 +69,17 @@ W1080, H1080 = 1920, 1080
 GLZ_WINDOW = 16 * 1024 * 1024
 
 
+def device_free_bytes(local_rank):
+    """free memory of this rank's GPU, or 0 when it cannot be told"""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            return int(torch.cuda.mem_get_info(local_rank % torch.cuda.device_count())[0])
+    except Exception:
+        pass
+    return 0
+
+
 class GlzWorkload:
     name = "glz1080"
     dtype = "u8"
@@ -78,6 +89,16 @@ class GlzWorkload:
         from spice_amd import frames
         self.B, self.gpu = B, gpu
         self.S = args.sessions
+        # a session holds its window's pixels (68 MiB), its hash table (8 MiB) and an output
+        # buffer of the worst-case size (10 MB): do not ask for more sessions than the GPU has room for
+        free = device_free_bytes(rank)
+        if free:
+            pool_bytes = max(1, min(args.pool, self.S)) * (args.warmup + args.steps) * W1080 * H1080 * 4
+            fit = int((free - pool_bytes - (4 << 30)) // (96 << 20))
+            if fit < self.S:
+                print("bench: %d sessions do not fit %.0f GB of free device memory, running %d"
+                      % (self.S, free / 1e9, max(1, fit)), file=sys.stderr, flush=True)
+                self.S = max(1, fit)
         self.nframes = args.warmup + args.steps
         pool = max(1, min(args.pool, self.S))
         t0 = time.time()
@@ -114,7 +135,8 @@ class GlzWorkload:
     def config(self, args):
         return {"workload": "glz1080: 1920x1080 RGB32 desktop-like frames, GLZ, one 16 Mi-pixel "
                             "dictionary window per session (BASELINE configs[1])",
-                "sessions_per_gpu": self.S, "frames_per_session": args.steps,
+                "sessions_per_gpu": self.S, "sessions_requested": args.sessions,
+                "frames_per_session": args.steps,
                 "distinct_sequences_per_gpu": self.pool, "parallelism": "session-sharded"}
 
     def roofline(self, times, steps, out_bytes_timed):
