@@ -19,7 +19,7 @@ def batch_encode(dev, items):
         px = np.ascontiguousarray(px)
         stride = px.shape[1]
         d_px = dev.to_device(px)
-        cap = max(4096, w * h * 4 + 2048)
+        cap = dev.L.spice_gpu_jpeg_out_bound(w, h)
         d_out = dev.malloc(cap)
         first = d_px if sign > 0 else d_px + (h - 1) * stride
         jobs.append(dict(pixels=first, format=fmt, width=w, height=h, stride=sign * stride,
