@@ -39,8 +39,12 @@
 
 #ifdef SPICE_WAVE_SIM
 #define JPEG_GLOBAL
+#define JPEG_CONST
+#define JPEG_FOUR_PER_CU
 #else
 #define JPEG_GLOBAL __attribute__((address_space(1)))
+#define JPEG_CONST __attribute__((address_space(4))) /* read through the scalar cache */
+#define JPEG_FOUR_PER_CU __attribute__((amdgpu_waves_per_eu(4, 4)))
 #endif
 
 /* zigzag position -> natural index */
@@ -351,8 +355,6 @@ __device__ void jpeg_strip_body(const JpegDevJob &job, const uint32_t *huff_g, i
     uint32_t *const coef = (uint32_t *)pool;
     __shared__ int dcq[JSLOTS * 6];
     __shared__ uint32_t huff[JHUFF_WORDS];
-    __shared__ int divs[128];                 /* divisors, luma then chroma */
-    __shared__ float rcps[128];
     __shared__ uint32_t rings[(JT / 64) * JRING_WORDS];
 
     const int tid = (int)threadIdx.x;
@@ -369,10 +371,6 @@ __device__ void jpeg_strip_body(const JpegDevJob &job, const uint32_t *huff_g, i
 
     for (int i = tid; i < JHUFF_WORDS; i += JT) {
         huff[i] = huff_g[i];
-    }
-    if (tid < 128) {
-        divs[tid] = tid < 64 ? job.div_y[tid] : job.div_c[tid - 64];
-        rcps[tid] = tid < 64 ? job.rcp_y[tid] : job.rcp_c[tid - 64];
     }
     for (int i = tid; i < (JT / 64) * JRING_WORDS; i += JT) {
         rings[i] = 0;
@@ -450,12 +448,26 @@ __device__ void jpeg_strip_body(const JpegDevJob &job, const uint32_t *huff_g, i
     __syncthreads(); /* last read of the tiles; the coefficients overwrite them */
     if (have && real) {
         jpeg_fdct<IFAST>(c);
-        const int *dv = divs + (bidx < 4 ? 0 : 64);
-        const float *rc = rcps + (bidx < 4 ? 0 : 64);
+    }
+    /* The divisors come through the scalar unit, a table at a time: luma lanes
+     * first, then chroma lanes (only one wavefront of the four holds both), so
+     * no vector register is spent on the 128 constants. */
 #pragma unroll
-        for (int i = 0; i < 64; i++) {
-            c[i] = jpeg_quant(c[i], dv[i], rc[i]);
+    for (int pass = 0; pass < 2; pass++) {
+        const bool mine = have && real && ((bidx < 4) == (pass == 0));
+        if (__ballot(mine) == 0) {
+            continue;
         }
+        const JPEG_CONST int *dv = (const JPEG_CONST int *)(uintptr_t)(pass == 0 ? job.div_y : job.div_c);
+        const JPEG_CONST float *rc = (const JPEG_CONST float *)(uintptr_t)(pass == 0 ? job.rcp_y : job.rcp_c);
+        if (mine) {
+#pragma unroll
+            for (int i = 0; i < 64; i++) {
+                c[i] = jpeg_quant(c[i], dv[i], rc[i]);
+            }
+        }
+    }
+    if (have && real) {
         dcq[slot * 6 + bidx] = c[0];
     } else {
 #pragma unroll
@@ -593,8 +605,9 @@ __device__ void jpeg_strip_body(const JpegDevJob &job, const uint32_t *huff_g, i
     }
 }
 
+/* Four workgroups per CU: 128 VGPRs (a few dwords of the DCT spill) and 37 KB of LDS each. */
 template <bool IFAST>
-__global__ void __launch_bounds__(JT)
+__global__ void __launch_bounds__(JT) JPEG_FOUR_PER_CU
 jpeg_strip_kernel(const JpegDevJob *jobs, const uint32_t *huff)
 {
     const JpegDevJob &job = jobs[blockIdx.y];
