@@ -527,8 +527,125 @@ __device__ void jpeg_strip_body(const JpegDevJob &job, const uint32_t *huff_g, i
         uint32_t bits = 0, flushed = 0; /* stream bits so far; words already in the slot */
 
         const uint32_t zrl = huff[0xf0], zrl_c = huff[256 + 0xf0];
-        int vnext = m0 < m1 ? (int)(int16_t)coef16[m0 * 6 * (JCOEF_STRIDE * 2) + lane] : 0;
-        for (int b = m0 * 6; b < m1 * 6; b++) {
+
+        /* The whole strip at once, a lane per block: each lane walks its block's
+         * coefficients in zigzag order, builds the block's code string in a
+         * 64-bit register and learns its length; a scan over the lanes places
+         * the strings.  Taken when the strip's bits fit the ring (video content
+         * does, at a few tens of bits per block); blocks longer than 64 bits are
+         * walked a second time and written code by code. */
+        const int nblk = (m1 - m0) * 6;
+        bool strip_done = false;
+        {
+            const bool on = lane < nblk;
+            const int bi = lane % 6;
+            const int ac_off = bi < 4 ? 0 : 256, dc_off = bi < 4 ? 512 : 528;
+            const uint32_t z = bi < 4 ? zrl : zrl_c;
+            const int zl = (int)(z >> 16);
+            const uint32_t *cw = coef + (m0 * 6 + (on ? lane : 0)) * JCOEF_STRIDE;
+            int len = 0;
+            uint64_t acc = 0;
+            int run = 0;
+            if (on) {
+                int kprev = 0; /* zigzag index of the last coefficient coded */
+#pragma unroll
+                for (int w = 0; w < 32; w++) {
+                    const uint32_t x = cw[w];
+                    if (w > 0 && x == 0) {
+                        continue;
+                    }
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const int k = 2 * w + h;
+                        const int v = h ? (int)x >> 16 : (int)(int16_t)x;
+                        if (k > 0 && v == 0) {
+                            continue;
+                        }
+                        const int t = v < 0 ? -v : v;
+                        const int nb = 32 - __clz(t);
+                        const uint32_t vbits = (uint32_t)(v + (v >> 31)) & ((1u << nb) - 1);
+                        if (k == 0) {
+                            const uint32_t e = huff[dc_off + nb];
+                            len = (int)(e >> 16) + nb;
+                            acc = ((e & 0xffff) << nb) | vbits;
+                        } else {
+                            const int r = k - 1 - kprev;
+                            const uint32_t e = huff[ac_off + ((r & 15) << 4) + nb];
+                            const int el = (int)(e >> 16) + nb;
+                            const int nz16 = r >> 4;
+                            for (int i = 0; i < nz16; i++) {
+                                acc = (acc << zl) | (z & 0xffff);
+                            }
+                            acc = (acc << el) | (((e & 0xffff) << nb) | vbits);
+                            len += nz16 * zl + el;
+                            kprev = k;
+                        }
+                    }
+                }
+                if (kprev != 63) {
+                    const uint32_t eob = huff[ac_off];
+                    acc = (acc << (eob >> 16)) | (eob & 0xffff);
+                    len += (int)(eob >> 16);
+                }
+            }
+            const uint32_t inc = wave_scan_inclusive((uint32_t)len, lane);
+            const uint32_t total = wave_broadcast(inc, 63);
+            if (total <= JRING_WORDS * 32) {
+                const uint32_t pos0 = inc - (uint32_t)len;
+                if (len > 0 && len <= 64) {
+                    if (len > 32) {
+                        jpeg_ring_put(ring, pos0, (uint32_t)(acc >> 32), len - 32);
+                        jpeg_ring_put(ring, pos0 + (uint32_t)(len - 32), (uint32_t)acc, 32);
+                    } else {
+                        jpeg_ring_put(ring, pos0, (uint32_t)acc, len);
+                    }
+                }
+                if (__ballot(len > 64) != 0) {
+                    if (len > 64) {
+                        uint32_t pos = pos0;
+                        run = 0;
+                        for (int k = 0; k < 64; k++) {
+                            const int v = (int)(int16_t)coef16[(m0 * 6 + lane) * (JCOEF_STRIDE * 2) + k];
+                            const int t = v < 0 ? -v : v;
+                            const int nb = 32 - __clz(t);
+                            const uint32_t vbits = (uint32_t)(v + (v >> 31)) & ((1u << nb) - 1);
+                            if (k == 0) {
+                                const uint32_t e = huff[dc_off + nb];
+                                jpeg_ring_put(ring, pos, ((e & 0xffff) << nb) | vbits, (int)(e >> 16) + nb);
+                                pos += (e >> 16) + (uint32_t)nb;
+                            } else if (v != 0) {
+                                for (int i = run >> 4; i > 0; i--) {
+                                    jpeg_ring_put(ring, pos, z & 0xffff, zl);
+                                    pos += (uint32_t)zl;
+                                }
+                                const uint32_t e = huff[ac_off + ((run & 15) << 4) + nb];
+                                jpeg_ring_put(ring, pos, ((e & 0xffff) << nb) | vbits, (int)(e >> 16) + nb);
+                                pos += (e >> 16) + (uint32_t)nb;
+                                run = 0;
+                            } else {
+                                run++;
+                            }
+                        }
+                        if (run) {
+                            const uint32_t eob = huff[ac_off];
+                            jpeg_ring_put(ring, pos, eob & 0xffff, (int)(eob >> 16));
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                for (uint32_t i = (uint32_t)lane; i < (total + 31) >> 5; i += 64) {
+                    const uint32_t w = ring[i];
+                    ring[i] = 0;
+                    out_words[i] = (w >> 24) | ((w >> 8) & 0xff00) | ((w << 8) & 0xff0000) | (w << 24);
+                }
+                __builtin_amdgcn_wave_barrier();
+                bits = total;
+                strip_done = true;
+            }
+        }
+
+        int vnext = m0 < m1 && !strip_done ? (int)(int16_t)coef16[m0 * 6 * (JCOEF_STRIDE * 2) + lane] : 0;
+        for (int b = m0 * 6; b < m1 * 6 && !strip_done; b++) {
             const int bi = b % 6;
             const int v = vnext;
             if (b + 1 < m1 * 6) {
