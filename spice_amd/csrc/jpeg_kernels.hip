@@ -342,7 +342,7 @@ __device__ __forceinline__ void jpeg_load_tiles(const JpegDevJob &job, uint8_t *
 }
 
 template <bool IFAST>
-__device__ void jpeg_strip_body(const JpegDevJob &job, const uint32_t *huff_g, int group)
+__device__ __forceinline__ void jpeg_strip_body(const JpegDevJob &job, const uint32_t *huff_g, int group)
 {
     /* the pixel tiles are dead once every lane holds its block in registers, so the
      * coefficients take their place: 37 KB per workgroup, four workgroups per CU */
@@ -460,10 +460,27 @@ __device__ void jpeg_strip_body(const JpegDevJob &job, const uint32_t *huff_g, i
         }
         const JPEG_CONST int *dv = (const JPEG_CONST int *)(uintptr_t)(pass == 0 ? job.div_y : job.div_c);
         const JPEG_CONST float *rc = (const JPEG_CONST float *)(uintptr_t)(pass == 0 ? job.rcp_y : job.rcp_c);
+        /* |v| + d/2 < d rounds to zero; away from the low frequencies that holds
+         * for every block of the wavefront more often than not, and the division
+         * is skipped for all of them at once.  Lanes of the other table answer the
+         * votes with a constant "no": the compiler drops that loop (an inactive
+         * lane's vote reads as zero anyway), while the CPU wave simulator, where a
+         * vote waits for every lane of the wavefront, needs the calls to pair up. */
         if (mine) {
 #pragma unroll
             for (int i = 0; i < 64; i++) {
-                c[i] = jpeg_quant(c[i], dv[i], rc[i]);
+                const int d = dv[i];
+                const int thr = d - (d >> 1);
+                const bool stays = (unsigned)(c[i] + thr - 1) >= (unsigned)(2 * thr - 1);
+                if (i > 0 && __ballot(stays) == 0) {
+                    c[i] = 0;
+                } else {
+                    c[i] = jpeg_quant(c[i], d, rc[i]);
+                }
+            }
+        } else {
+            for (int i = 1; i < 64; i++) {
+                (void)__ballot(false);
             }
         }
     }
