@@ -341,6 +341,124 @@ __device__ __forceinline__ void jpeg_load_tiles(const JpegDevJob &job, uint8_t *
     }
 }
 
+/* One 2x2 quad the slow way, every coordinate clamped: the image's right and
+ * bottom edges, where MCUs hang over (same rules as jpeg_load_tiles). */
+template <int FMT>
+__device__ __forceinline__ void jpeg_quad_edge(const JpegDevJob &job, uint8_t *ytile, uint8_t *cbtile,
+                                               uint8_t *crtile, int slot, int qx, int qy, int mcx, int mcy)
+{
+    const int W = job.width, H = job.height;
+    const int ch = (H + 1) >> 1;
+    const int x = mcx * 16 + qx * 2, y = mcy * 16 + qy * 2;
+    const int cyc = min(mcy * 8 + qy, ch - 1);
+    const int r0 = min(2 * cyc, H - 1), r1 = min(2 * cyc + 1, H - 1);
+    const int c0 = min(x, W - 1), c1 = min(x + 1, W - 1);
+    const uint32_t p00 = jpeg_fetch_rgb<FMT>(job, c0, r0), p01 = jpeg_fetch_rgb<FMT>(job, c1, r0);
+    const uint32_t p10 = jpeg_fetch_rgb<FMT>(job, c0, r1), p11 = jpeg_fetch_rgb<FMT>(job, c1, r1);
+    const int bias = (qx & 1) ? 2 : 1;
+    cbtile[qy * CT_STRIDE + slot * 8 + qx] =
+        (uint8_t)((jpeg_cb(p00) + jpeg_cb(p01) + jpeg_cb(p10) + jpeg_cb(p11) + bias) >> 2);
+    crtile[qy * CT_STRIDE + slot * 8 + qx] =
+        (uint8_t)((jpeg_cr(p00) + jpeg_cr(p01) + jpeg_cr(p10) + jpeg_cr(p11) + bias) >> 2);
+    const int y0 = min(y, H - 1), y1 = min(y + 1, H - 1);
+    uint8_t *yp = &ytile[(qy * 2) * YT_STRIDE + slot * 16 + qx * 2];
+    yp[0] = (uint8_t)jpeg_y(jpeg_fetch_rgb<FMT>(job, c0, y0));
+    yp[1] = (uint8_t)jpeg_y(jpeg_fetch_rgb<FMT>(job, c1, y0));
+    yp[YT_STRIDE] = (uint8_t)jpeg_y(jpeg_fetch_rgb<FMT>(job, c0, y1));
+    yp[YT_STRIDE + 1] = (uint8_t)jpeg_y(jpeg_fetch_rgb<FMT>(job, c1, y1));
+}
+
+/* libjpeg jccolor.c on a pixel stored b,g,r,pad */
+__device__ __forceinline__ void jpeg_ycc_bgrx(uint32_t p, int &yy, int &cb, int &cr)
+{
+    const int b = p & 0xff, g = (p >> 8) & 0xff, r = (p >> 16) & 0xff;
+    yy = (19595 * r + 38470 * g + 7471 * b + 32768) >> 16;
+    cb = (-11059 * r - 21709 * g + (b << 15) + ((128 << 16) + 32767)) >> 16;
+    cr = ((r << 15) - 27439 * g - 5329 * b + ((128 << 16) + 32767)) >> 16;
+}
+
+/* Phase 1 for the 32-bit formats (b,g,r,pad): a lane takes four pixels of two
+ * rows at a time, 16 bytes a row in one request; all of a lane's requests are
+ * out before the first pixel is converted.  Items that touch the image's right
+ * or bottom edge go the clamped way, quad by quad. */
+__device__ __forceinline__ void jpeg_load_tiles32(const JpegDevJob &job, uint8_t *ytile, uint8_t *cbtile,
+                                                  uint8_t *crtile, int tid, int ns, bool has_halo, int hx,
+                                                  int hy, int mx0, int my)
+{
+    const int W = job.width, H = job.height;
+    const int cols = ns * 4; /* four-pixel columns of a tile row */
+    const float inv = 1.0f / (float)cols;
+    constexpr int ITERS = (JSLOTS * 4 * 8 + JT - 1) / JT;
+    uint32_t px[ITERS][8];
+    unsigned fast = 0;
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const int item = tid + it * JT;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            px[it][k] = 0;
+        }
+        if (item < cols * 8) {
+            /* item / cols; exact: the quotient is below 8 and cols below 2^8 */
+            const int qy = (int)(((float)item + 0.5f) * inv);
+            const int cx = item - qy * cols;
+            const int slot = cx >> 2;
+            const int mcx = slot == 0 ? hx : mx0 + slot - 1;
+            const int mcy = slot == 0 ? hy : my;
+            const int x = mcx * 16 + (cx & 3) * 4, y = mcy * 16 + qy * 2;
+            if ((slot != 0 || has_halo) && x + 3 < W && y + 1 < H) {
+                const JPEG_GLOBAL uint8_t *row =
+                    (const JPEG_GLOBAL uint8_t *)(uintptr_t)job.pixels + (int64_t)y * job.stride + x * 4;
+                const JPEG_GLOBAL uint32_t *a = (const JPEG_GLOBAL uint32_t *)row;
+                const JPEG_GLOBAL uint32_t *b = (const JPEG_GLOBAL uint32_t *)(row + job.stride);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    px[it][k] = a[k];
+                    px[it][4 + k] = b[k];
+                }
+                fast |= 1u << it;
+            }
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const int item = tid + it * JT;
+        if (item >= cols * 8) {
+            continue;
+        }
+        const int qy = (int)(((float)item + 0.5f) * inv);
+        const int cx = item - qy * cols;
+        const int slot = cx >> 2;
+        if (slot == 0 && !has_halo) {
+            continue;
+        }
+        if (fast & (1u << it)) {
+            int yy[8], cb[8], cr[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                jpeg_ycc_bgrx(px[it][k], yy[k], cb[k], cr[k]);
+            }
+            uint8_t *yp = &ytile[(qy * 2) * YT_STRIDE + slot * 16 + (cx & 3) * 4];
+            *(uint32_t *)yp = (uint32_t)yy[0] | ((uint32_t)yy[1] << 8) | ((uint32_t)yy[2] << 16) | ((uint32_t)yy[3] << 24);
+            *(uint32_t *)(yp + YT_STRIDE) =
+                (uint32_t)yy[4] | ((uint32_t)yy[5] << 8) | ((uint32_t)yy[6] << 16) | ((uint32_t)yy[7] << 24);
+            /* chroma column parity inside the MCU equals the global parity: bias 1, then 2 */
+            const uint32_t cb0 = (uint32_t)(cb[0] + cb[1] + cb[4] + cb[5] + 1) >> 2;
+            const uint32_t cb1 = (uint32_t)(cb[2] + cb[3] + cb[6] + cb[7] + 2) >> 2;
+            const uint32_t cr0 = (uint32_t)(cr[0] + cr[1] + cr[4] + cr[5] + 1) >> 2;
+            const uint32_t cr1 = (uint32_t)(cr[2] + cr[3] + cr[6] + cr[7] + 2) >> 2;
+            const int co = qy * CT_STRIDE + slot * 8 + (cx & 3) * 2;
+            *(uint16_t *)&cbtile[co] = (uint16_t)(cb0 | (cb1 << 8));
+            *(uint16_t *)&crtile[co] = (uint16_t)(cr0 | (cr1 << 8));
+        } else {
+            const int mcx = slot == 0 ? hx : mx0 + slot - 1;
+            const int mcy = slot == 0 ? hy : my;
+            jpeg_quad_edge<8>(job, ytile, cbtile, crtile, slot, (cx & 3) * 2, qy, mcx, mcy);
+            jpeg_quad_edge<8>(job, ytile, cbtile, crtile, slot, (cx & 3) * 2 + 1, qy, mcx, mcy);
+        }
+    }
+}
+
 template <bool IFAST>
 __device__ __forceinline__ void jpeg_strip_body(const JpegDevJob &job, const uint32_t *huff_g, int group)
 {
@@ -380,7 +498,7 @@ __device__ __forceinline__ void jpeg_strip_body(const JpegDevJob &job, const uin
     switch (job.format) {
     case 8:
     case 9:
-        jpeg_load_tiles<8>(job, ytile, cbtile, crtile, tid, ns, has_halo, hx, hy, mx0, my);
+        jpeg_load_tiles32(job, ytile, cbtile, crtile, tid, ns, has_halo, hx, hy, mx0, my);
         break;
     case 7:
         jpeg_load_tiles<7>(job, ytile, cbtile, crtile, tid, ns, has_halo, hx, hy, mx0, my);
