@@ -113,6 +113,9 @@ __device__ __forceinline__ int jpeg_cr(uint32_t rgb)
 
 /* ------------------------------------------------------------------- DCTs */
 #define JDESCALE(x, n) (((x) + (1 << ((n) - 1))) >> (n))
+/* Samples are 8 bits, so every DCT operand stays below 2^17 and every constant
+ * below 2^15: the 24-bit multiplier gives the same low 32 bits at full rate. */
+#define JMUL(a, b) __mul24((a), (b))
 
 /* libjpeg jfdctint.c, one 8-point pass; FIRST: row pass (scale up by 4) */
 template <bool FIRST>
@@ -130,20 +133,20 @@ __device__ __forceinline__ void jpeg_islow_1d(int &d0, int &d1, int &d2, int &d3
         d0 = JDESCALE(t10 + t11, 2);
         d4 = JDESCALE(t10 - t11, 2);
     }
-    int z1 = (t12 + t13) * 4433;
-    d2 = JDESCALE(z1 + t13 * 6270, sh);
-    d6 = JDESCALE(z1 + t12 * (-15137), sh);
+    int z1 = JMUL(t12 + t13, 4433);
+    d2 = JDESCALE(z1 + JMUL(t13, 6270), sh);
+    d6 = JDESCALE(z1 + JMUL(t12, -15137), sh);
     z1 = t4 + t7;
     int z2 = t5 + t6, z3 = t4 + t6, z4 = t5 + t7;
-    const int z5 = (z3 + z4) * 9633;
-    t4 *= 2446;
-    t5 *= 16819;
-    t6 *= 25172;
-    t7 *= 12299;
-    z1 *= -7373;
-    z2 *= -20995;
-    z3 = z3 * (-16069) + z5;
-    z4 = z4 * (-3196) + z5;
+    const int z5 = JMUL(z3 + z4, 9633);
+    t4 = JMUL(t4, 2446);
+    t5 = JMUL(t5, 16819);
+    t6 = JMUL(t6, 25172);
+    t7 = JMUL(t7, 12299);
+    z1 = JMUL(z1, -7373);
+    z2 = JMUL(z2, -20995);
+    z3 = JMUL(z3, -16069) + z5;
+    z4 = JMUL(z4, -3196) + z5;
     d7 = JDESCALE(t4 + z1 + z3, sh);
     d5 = JDESCALE(t5 + z2 + z4, sh);
     d3 = JDESCALE(t6 + z2 + z3, sh);
@@ -159,16 +162,16 @@ __device__ __forceinline__ void jpeg_ifast_1d(int &d0, int &d1, int &d2, int &d3
     int t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
     d0 = t10 + t11;
     d4 = t10 - t11;
-    const int z1 = ((t12 + t13) * 181) >> 8;
+    const int z1 = JMUL(t12 + t13, 181) >> 8;
     d2 = t13 + z1;
     d6 = t13 - z1;
     t10 = t4 + t5;
     t11 = t5 + t6;
     t12 = t6 + t7;
-    const int z5 = ((t10 - t12) * 98) >> 8;
-    const int z2 = ((t10 * 139) >> 8) + z5;
-    const int z4 = ((t12 * 334) >> 8) + z5;
-    const int z3 = (t11 * 181) >> 8;
+    const int z5 = JMUL(t10 - t12, 98) >> 8;
+    const int z2 = (JMUL(t10, 139) >> 8) + z5;
+    const int z4 = (JMUL(t12, 334) >> 8) + z5;
+    const int z3 = JMUL(t11, 181) >> 8;
     const int z11 = t7 + z3, z13 = t7 - z3;
     d5 = z13 + z2;
     d3 = z13 - z2;
@@ -204,7 +207,7 @@ __device__ __forceinline__ int jpeg_quant(int v, int d, float rcp)
 {
     const unsigned a = (unsigned)(v < 0 ? -v : v) + ((unsigned)d >> 1);
     unsigned q = (unsigned)((float)a * rcp);
-    int rem = (int)(a - q * (unsigned)d);
+    int rem = (int)(a - __umul24(q, (unsigned)d));
     if (rem < 0) {
         q--;
         rem += d;

@@ -207,6 +207,7 @@ static inline unsigned __byte_perm(unsigned a, unsigned b, unsigned sel)
     return r;
 }
 static inline int __mul24(int a, int b) { return a * b; }
+static inline unsigned __umul24(unsigned a, unsigned b) { return a * b; }
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((uint64_t)a * b) >> 32); }
 
 /* fibers are cooperative, so plain read-modify-write is atomic here */
