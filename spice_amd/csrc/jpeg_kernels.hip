@@ -35,7 +35,7 @@
 #define YT_STRIDE (JSLOTS * 16)               /* bytes per luma tile row */
 #define CT_STRIDE (JSLOTS * 8)
 #define JCOEF_STRIDE 33                       /* words per block in LDS: 64 int16 + 1 against bank conflicts */
-#define JRING_WORDS 128                       /* per wavefront; a block adds at most 52 words */
+#define JRING_WORDS 256                       /* per wavefront; a block adds at most 52 words */
 
 #ifdef SPICE_WAVE_SIM
 #define JPEG_GLOBAL
@@ -466,7 +466,7 @@ template <bool IFAST>
 __device__ __forceinline__ void jpeg_strip_body(const JpegDevJob &job, const uint32_t *huff_g, int group)
 {
     /* the pixel tiles are dead once every lane holds its block in registers, so the
-     * coefficients take their place: 37 KB per workgroup, four workgroups per CU */
+     * coefficients take their place: with the tables and bit rings 39 KB per workgroup, four workgroups per CU */
     constexpr int kTileBytes = 16 * YT_STRIDE + 2 * 8 * CT_STRIDE;
     constexpr int kCoefBytes = JG_MCUS * 6 * JCOEF_STRIDE * 4;
     __shared__ __align__(16) uint8_t pool[kCoefBytes > kTileBytes ? kCoefBytes : kTileBytes];
@@ -860,7 +860,7 @@ __device__ __forceinline__ void jpeg_strip_body(const JpegDevJob &job, const uin
     }
 }
 
-/* Four workgroups per CU: 128 VGPRs (a few dwords of the DCT spill) and 37 KB of LDS each. */
+/* Four workgroups per CU: 128 VGPRs (a few dwords of the DCT spill) and 39 KB of LDS each. */
 template <bool IFAST>
 __global__ void __launch_bounds__(JT) JPEG_FOUR_PER_CU
 jpeg_strip_kernel(const JpegDevJob *jobs, const uint32_t *huff)

@@ -9,7 +9,7 @@ else:
     gpu=spice_amd.load(0)
 W,H=3840,2160
 F=16
-seq=frames.VideoSequence(W,H,seed=7)
+seq=frames.DesktopSequence(W,H,seed=3) if os.environ.get('CONTENT')=='desktop' else frames.VideoSequence(W,H,seed=7)
 fr=[seq.next() for _ in range(4)]
 dev=[gpu.to_device(f) for f in fr]
 cap=W*H
