@@ -269,8 +269,9 @@ __device__ __forceinline__ int jpeg_block_scan(int v, int *wave_sums, int tid, i
 /* huff: [0..255] AC luma, [256..511] AC chroma, [512..527] DC luma, [528..543] DC chroma */
 #define JHUFF_WORDS 544
 
-/* Phase 1 of the strip kernel for one pixel format: the group's pixels (and
- * its halo MCU's) become luma and 2x2-averaged chroma samples in the LDS tiles. */
+/* Phase 1 of the strip kernel for one pixel format, a pixel per request: the
+ * group's pixels (and its halo MCU's) become luma and 2x2-averaged chroma
+ * samples in the LDS tiles. */
 template <int FMT>
 __device__ __forceinline__ void jpeg_load_tiles(const JpegDevJob &job, uint8_t *ytile, uint8_t *cbtile,
                                                 uint8_t *crtile, int tid, int ns, bool has_halo, int hx,
@@ -380,25 +381,69 @@ __device__ __forceinline__ void jpeg_ycc_bgrx(uint32_t p, int &yy, int &cb, int 
     cr = ((r << 15) - 27439 * g - 5329 * b + ((128 << 16) + 32767)) >> 16;
 }
 
-/* Phase 1 for the 32-bit formats (b,g,r,pad): a lane takes four pixels of two
- * rows at a time, 16 bytes a row in one request; all of a lane's requests are
- * out before the first pixel is converted.  Items that touch the image's right
- * or bottom edge go the clamped way, quad by quad. */
-__device__ __forceinline__ void jpeg_load_tiles32(const JpegDevJob &job, uint8_t *ytile, uint8_t *cbtile,
-                                                  uint8_t *crtile, int tid, int ns, bool has_halo, int hx,
-                                                  int hy, int mx0, int my)
+/* Four stored pixels from the words of a row piece (4, 3 or 2 words by format) */
+template <int FMT>
+__device__ __forceinline__ void jpeg_unpack4(const uint32_t *w, uint32_t *raw)
 {
+    if (FMT == 8 || FMT == 9) {
+        raw[0] = w[0];
+        raw[1] = w[1];
+        raw[2] = w[2];
+        raw[3] = w[3];
+    } else if (FMT == 7 || FMT == JPEG_FMT_RGB24) {
+        raw[0] = w[0] & 0xffffffu;
+        raw[1] = (w[0] >> 24) | ((w[1] & 0xffffu) << 8);
+        raw[2] = (w[1] >> 16) | ((w[2] & 0xffu) << 16);
+        raw[3] = w[2] >> 8;
+    } else {
+        raw[0] = w[0] & 0xffffu;
+        raw[1] = w[0] >> 16;
+        raw[2] = w[1] & 0xffffu;
+        raw[3] = w[1] >> 16;
+    }
+}
+
+template <int FMT>
+__device__ __forceinline__ void jpeg_ycc(uint32_t raw, int &yy, int &cb, int &cr)
+{
+    if (FMT == 8 || FMT == 9) {
+        jpeg_ycc_bgrx(raw, yy, cb, cr);
+    } else {
+        const uint32_t rgb = jpeg_raw_to_rgb<FMT>(raw);
+        yy = jpeg_y(rgb);
+        cb = jpeg_cb(rgb);
+        cr = jpeg_cr(rgb);
+    }
+}
+
+/* Phase 1, the wide way: a lane takes four pixels of two rows at a time, each
+ * row piece (16, 12 or 8 bytes) in one request; all of a lane's requests are
+ * out before the first pixel is converted.  Items that touch the image's right
+ * or bottom edge go the clamped way, quad by quad.  A 16- or 24-bit image whose
+ * rows do not start on 4-byte boundaries (a stream's sub-rectangle can start
+ * anywhere) is loaded pixel by pixel instead. */
+template <int FMT>
+__device__ __forceinline__ void jpeg_load_tiles_wide(const JpegDevJob &job, uint8_t *ytile, uint8_t *cbtile,
+                                                     uint8_t *crtile, int tid, int ns, bool has_halo, int hx,
+                                                     int hy, int mx0, int my)
+{
+    constexpr int PXB = (FMT == 8 || FMT == 9) ? 4 : (FMT == 7 || FMT == JPEG_FMT_RGB24) ? 3 : 2;
+    constexpr int NW = PXB; /* words in four pixels */
     const int W = job.width, H = job.height;
+    if (PXB != 4 && (((uint64_t)(uintptr_t)job.pixels | (uint64_t)job.stride) & 3) != 0) {
+        jpeg_load_tiles<FMT>(job, ytile, cbtile, crtile, tid, ns, has_halo, hx, hy, mx0, my);
+        return;
+    }
     const int cols = ns * 4; /* four-pixel columns of a tile row */
     const float inv = 1.0f / (float)cols;
     constexpr int ITERS = (JSLOTS * 4 * 8 + JT - 1) / JT;
-    uint32_t px[ITERS][8];
+    uint32_t px[ITERS][2 * NW];
     unsigned fast = 0;
 #pragma unroll
     for (int it = 0; it < ITERS; it++) {
         const int item = tid + it * JT;
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
+        for (int k = 0; k < 2 * NW; k++) {
             px[it][k] = 0;
         }
         if (item < cols * 8) {
@@ -411,13 +456,13 @@ __device__ __forceinline__ void jpeg_load_tiles32(const JpegDevJob &job, uint8_t
             const int x = mcx * 16 + (cx & 3) * 4, y = mcy * 16 + qy * 2;
             if ((slot != 0 || has_halo) && x + 3 < W && y + 1 < H) {
                 const JPEG_GLOBAL uint8_t *row =
-                    (const JPEG_GLOBAL uint8_t *)(uintptr_t)job.pixels + (int64_t)y * job.stride + x * 4;
+                    (const JPEG_GLOBAL uint8_t *)(uintptr_t)job.pixels + (int64_t)y * job.stride + x * PXB;
                 const JPEG_GLOBAL uint32_t *a = (const JPEG_GLOBAL uint32_t *)row;
                 const JPEG_GLOBAL uint32_t *b = (const JPEG_GLOBAL uint32_t *)(row + job.stride);
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
+                for (int k = 0; k < NW; k++) {
                     px[it][k] = a[k];
-                    px[it][4 + k] = b[k];
+                    px[it][NW + k] = b[k];
                 }
                 fast |= 1u << it;
             }
@@ -436,10 +481,13 @@ __device__ __forceinline__ void jpeg_load_tiles32(const JpegDevJob &job, uint8_t
             continue;
         }
         if (fast & (1u << it)) {
+            uint32_t raw[8];
+            jpeg_unpack4<FMT>(&px[it][0], &raw[0]);
+            jpeg_unpack4<FMT>(&px[it][NW], &raw[4]);
             int yy[8], cb[8], cr[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                jpeg_ycc_bgrx(px[it][k], yy[k], cb[k], cr[k]);
+                jpeg_ycc<FMT>(raw[k], yy[k], cb[k], cr[k]);
             }
             uint8_t *yp = &ytile[(qy * 2) * YT_STRIDE + slot * 16 + (cx & 3) * 4];
             *(uint32_t *)yp = (uint32_t)yy[0] | ((uint32_t)yy[1] << 8) | ((uint32_t)yy[2] << 16) | ((uint32_t)yy[3] << 24);
@@ -456,8 +504,8 @@ __device__ __forceinline__ void jpeg_load_tiles32(const JpegDevJob &job, uint8_t
         } else {
             const int mcx = slot == 0 ? hx : mx0 + slot - 1;
             const int mcy = slot == 0 ? hy : my;
-            jpeg_quad_edge<8>(job, ytile, cbtile, crtile, slot, (cx & 3) * 2, qy, mcx, mcy);
-            jpeg_quad_edge<8>(job, ytile, cbtile, crtile, slot, (cx & 3) * 2 + 1, qy, mcx, mcy);
+            jpeg_quad_edge<FMT>(job, ytile, cbtile, crtile, slot, (cx & 3) * 2, qy, mcx, mcy);
+            jpeg_quad_edge<FMT>(job, ytile, cbtile, crtile, slot, (cx & 3) * 2 + 1, qy, mcx, mcy);
         }
     }
 }
@@ -501,16 +549,16 @@ __device__ __forceinline__ void jpeg_strip_body(const JpegDevJob &job, const uin
     switch (job.format) {
     case 8:
     case 9:
-        jpeg_load_tiles32(job, ytile, cbtile, crtile, tid, ns, has_halo, hx, hy, mx0, my);
+        jpeg_load_tiles_wide<8>(job, ytile, cbtile, crtile, tid, ns, has_halo, hx, hy, mx0, my);
         break;
     case 7:
-        jpeg_load_tiles<7>(job, ytile, cbtile, crtile, tid, ns, has_halo, hx, hy, mx0, my);
+        jpeg_load_tiles_wide<7>(job, ytile, cbtile, crtile, tid, ns, has_halo, hx, hy, mx0, my);
         break;
     case JPEG_FMT_RGB24:
-        jpeg_load_tiles<JPEG_FMT_RGB24>(job, ytile, cbtile, crtile, tid, ns, has_halo, hx, hy, mx0, my);
+        jpeg_load_tiles_wide<JPEG_FMT_RGB24>(job, ytile, cbtile, crtile, tid, ns, has_halo, hx, hy, mx0, my);
         break;
     default:
-        jpeg_load_tiles<6>(job, ytile, cbtile, crtile, tid, ns, has_halo, hx, hy, mx0, my);
+        jpeg_load_tiles_wide<6>(job, ytile, cbtile, crtile, tid, ns, has_halo, hx, hy, mx0, my);
         break;
     }
     __syncthreads();

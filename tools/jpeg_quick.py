@@ -11,12 +11,15 @@ W,H=3840,2160
 F=16
 seq=frames.DesktopSequence(W,H,seed=3) if os.environ.get('CONTENT')=='desktop' else frames.VideoSequence(W,H,seed=7)
 fr=[seq.next() for _ in range(4)]
+fmt,bpp=B.BITMAP_FMT_32BIT,4
+if os.environ.get('FMT')=='24': fr=[frames.to_bgr24(f) for f in fr]; fmt,bpp=B.BITMAP_FMT_24BIT,3
+if os.environ.get('FMT')=='16': fr=[frames.to_rgb16(f) for f in fr]; fmt,bpp=B.BITMAP_FMT_16BIT,2
 dev=[gpu.to_device(f) for f in fr]
 cap=W*H
 outs=[gpu.malloc(cap) for _ in range(F)]
 dct=int(sys.argv[1]) if len(sys.argv)>1 else B.DCT_IFAST
 q=70 if dct==B.DCT_IFAST else 85
-items=[dict(pixels=dev[f%4],format=B.BITMAP_FMT_32BIT,width=W,height=H,stride=W*4,quality=q,dct=dct,out=outs[f],out_capacity=cap) for f in range(F)]
+items=[dict(pixels=dev[f%4],format=fmt,width=W,height=H,stride=W*bpp,quality=q,dct=dct,out=outs[f],out_capacity=cap) for f in range(F)]
 try:
     B.jpeg_encode_batch(gpu,items)
 except Exception as e:
