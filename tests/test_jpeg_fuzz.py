@@ -66,3 +66,63 @@ def test_sim_jpeg_fuzz(sim, oracle, seed):
 @pytest.mark.parametrize("seed", range(50, 58))
 def test_gpu_jpeg_fuzz(gpu, oracle, seed):
     run_fuzz(gpu, oracle, seed, 60, 900, 500)
+
+
+def run_alignment(dev, oracle):
+    """16- and 24-bit rows that start on 4-byte boundaries take the wide pixel
+    loader, the others the per-pixel one; both against the same oracle."""
+    rng = np.random.default_rng(77)
+    items, wants = [], []
+    for w, h in ((72, 40), (71, 41), (70, 33), (64, 32), (37, 18)):
+        for fmt in (B.BITMAP_FMT_24BIT, B.BITMAP_FMT_16BIT):
+            im = frames.golden_image(max(w, 16), max(h, 16), "desktop", w)[:h, :w].copy()
+            px = frames.to_bgr24(im) if fmt == B.BITMAP_FMT_24BIT else frames.to_rgb16(im, rng)
+            for sign in (1, -1):
+                items.append((px, w, h, fmt, 70, 1, sign))
+                rows = px if sign > 0 else np.ascontiguousarray(px[::-1])
+                wants.append(oracle.jpeg_encode(rows, w, h, px.shape[1], FMT_O[fmt], 70, 1))
+    for it, want, got in zip(items, wants, batch_encode(dev, items)):
+        assert_same_stream(want, got, "%dx%d fmt %d sign %d" % (it[1], it[2], it[3], it[6]))
+
+
+def test_sim_row_alignment(sim, oracle):
+    run_alignment(sim, oracle)
+
+
+@pytest.mark.gpu
+def test_gpu_row_alignment(gpu, oracle):
+    run_alignment(gpu, oracle)
+
+
+def run_density_sweep(dev, oracle, qualities):
+    """One-strip images (10 MCUs) whose bit counts sweep from a few hundred to
+    tens of thousands: the strip-at-once Huffman path, its code-by-code walk for
+    blocks over 64 bits, and the block-at-a-time path past the bit ring's size."""
+    rng = np.random.default_rng(5)
+    items, wants = [], []
+    for amp in (2, 6, 16, 40, 100):
+        noise = rng.integers(-amp, amp + 1, (32, 176, 3))
+        im = np.zeros((32, 176, 4), np.uint8)
+        im[..., :3] = np.clip(128 + noise, 0, 255)
+        px = im.reshape(32, 176 * 4)
+        for q in qualities:
+            for dct in (0, 1):
+                items.append((px, 176, 32, B.BITMAP_FMT_32BIT, q, dct, 1))
+                wants.append(oracle.jpeg_encode(px, 176, 32, px.shape[1], 8, q, dct))
+    sizes = set()
+    for it, want, got in zip(items, wants, batch_encode(dev, items)):
+        assert_same_stream(want, got, "q %d dct %d" % (it[4], it[5]))
+        sizes.add(len(want))
+    return sizes
+
+
+def test_sim_density_sweep(sim, oracle):
+    sizes = run_density_sweep(sim, oracle, range(4, 100, 12))
+    # header ~600 bytes, 132 blocks: from a few bits a block to over 200 (a full
+    # strip of 60 such blocks is past the 8192-bit ring)
+    assert min(sizes) < 1000 and max(sizes) > 4000, (min(sizes), max(sizes))
+
+
+@pytest.mark.gpu
+def test_gpu_density_sweep(gpu, oracle):
+    run_density_sweep(gpu, oracle, range(2, 101, 2))
