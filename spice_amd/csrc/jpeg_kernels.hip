@@ -510,6 +510,8 @@ __device__ __forceinline__ void jpeg_load_tiles_wide(const JpegDevJob &job, uint
     }
 }
 
+/* Always inlined: the kernel's register limit (JPEG_FOUR_PER_CU) is an attribute of
+ * the kernel function and would not reach this body if it were called. */
 template <bool IFAST>
 __device__ __forceinline__ void jpeg_strip_body(const JpegDevJob &job, const uint32_t *huff_g, int group)
 {
