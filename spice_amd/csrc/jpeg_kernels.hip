@@ -979,38 +979,85 @@ jpeg_gather_kernel(const JpegDevJob *jobs)
             uint64_t soff = job.strip_bitoff[s];
             uint32_t sbits = job.strip_bits[s];
             const uint8_t *sp = job.strip_buf + (size_t)s * job.strip_stride;
-            uint32_t out4[4] = {0, 0, 0, 0};
-            for (int k = 0; k < 16; k++) {
-                uint32_t byte = 0;
-                int got = 0;
-                if (j0 + (uint64_t)k < nbytes) {
-                    while (got < 8) {
-                        if (bit >= tbits) {
-                            byte |= (1u << (8 - got)) - 1; /* pad with ones */
-                            got = 8;
-                            break;
-                        }
-                        while (bit >= soff + sbits) {
-                            s++;
-                            soff = job.strip_bitoff[s];
-                            sbits = job.strip_bits[s];
-                            sp = job.strip_buf + (size_t)s * job.strip_stride;
-                        }
-                        const uint32_t local = (uint32_t)(bit - soff);
-                        const int avail = (int)(sbits - local);
-                        const int take = min(8 - got, avail);
-                        const uint32_t o = local >> 3, sh = local & 7;
-                        const uint32_t two = ((uint32_t)sp[o] << 8) | (uint32_t)sp[o + 1];
-                        const uint32_t bits8 = (two >> (8 - sh)) & 0xff; /* 8 bits from `local` */
-                        byte |= (bits8 >> (8 - take)) << (8 - got - take);
-                        got += take;
-                        bit += (uint64_t)take;
+            /* The lane's 128 stream bits, most significant first in acc[0..3], a
+             * strip's share at a time: five words of the strip's slot read as
+             * big-endian numbers, aligned to the first wanted bit, cut to the
+             * bits the strip still has, and ORed in behind what is there. */
+            uint32_t acc[4] = {0, 0, 0, 0};
+            int have = 0;
+            const int want = (int)(nbytes - j0 < 16 ? nbytes - j0 : 16) * 8;
+            while (have < want) {
+                if (bit >= tbits) {
+                    break; /* the rest is padding */
+                }
+                while (bit >= soff + sbits) {
+                    s++;
+                    soff = job.strip_bitoff[s];
+                    sbits = job.strip_bits[s];
+                    sp = job.strip_buf + (size_t)s * job.strip_stride;
+                }
+                const uint32_t local = (uint32_t)(bit - soff);
+                const int left = (int)(sbits - local);
+                const int take = left < want - have ? left : want - have;
+                const uint32_t *wp = (const uint32_t *)(sp + ((local >> 3) & ~3u));
+                const uint32_t t = local & 31;
+                uint32_t v[4];
+                {
+                    uint32_t be[5];
+#pragma unroll
+                    for (int i = 0; i < 5; i++) {
+                        be[i] = __builtin_bswap32(wp[i]);
                     }
-                    if (byte == 0xff) {
-                        ff++;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        v[i] = t ? (be[i] << t) | (be[i + 1] >> (32 - t)) : be[i];
                     }
                 }
-                out4[k >> 2] |= byte << (8 * (k & 3));
+                /* keep the first `take` bits */
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int keep = take - 32 * i;
+                    v[i] = keep >= 32 ? v[i] : keep <= 0 ? 0u : v[i] & ~(0xffffffffu >> keep);
+                }
+                /* shift right by `have` bits into place */
+                const int ws = have >> 5, bs = have & 31;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int j = i - ws;
+                    uint32_t x = 0;
+                    if (j >= 0) {
+                        x = v[j] >> bs;
+                        if (bs && j >= 1) {
+                            x |= v[j - 1] << (32 - bs);
+                        }
+                    }
+                    acc[i] |= x;
+                }
+                have += take;
+                bit += (uint64_t)take;
+            }
+            if (have < want) {
+                /* pad with ones */
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int keep = have - 32 * i;
+                    acc[i] |= keep >= 32 ? 0u : keep <= 0 ? 0xffffffffu : 0xffffffffu >> keep;
+                }
+            }
+            uint32_t out4[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                /* bytes past the stream's end stay zero, as before */
+                const int nb = want / 8 - 4 * i;
+                const uint32_t vis = nb >= 4 ? acc[i] : nb <= 0 ? 0u : acc[i] & ~(0xffffffffu >> (8 * nb));
+                /* bytes equal to 0xff: the zero bytes of ~vis among the nb real ones */
+                const uint32_t n = ~vis;
+                uint32_t z = ~(((n & 0x7f7f7f7fu) + 0x7f7f7f7fu) | n | 0x7f7f7f7fu);
+                if (nb < 4) {
+                    z = nb <= 0 ? 0u : z & ~(0xffffffffu >> (8 * nb));
+                }
+                ff += __popc(z);
+                out4[i] = __builtin_bswap32(vis);
             }
             *(uint4 *)(job.scan_buf + j0) = make_uint4(out4[0], out4[1], out4[2], out4[3]);
         }
