@@ -40,7 +40,7 @@
 #define GLZ_WAVE 64
 #define GLZ_THREADS 256
 #define GLZ_WIN 256                       /* window positions per step */
-#define GLZ_K 16                          /* pixels every lane pre-compares against a candidate */
+#define GLZ_K 8                           /* pixels every lane pre-compares against a candidate; above every type's MAX_REF */
 #define GLZ_TILE (GLZ_WIN + GLZ_K + 4)    /* LDS pixels: positions ip-1 .. ip+WIN+K+2 */
 #define GLZ_SEG_CACHE 64                  /* segment slots mirrored in LDS */
 #define GLZ_KEYS 256                      /* rows of the same-hash bitmap */
@@ -76,10 +76,10 @@
  * global loads and values read at a wave-uniform address stay wave-uniform. */
 #ifdef SPICE_WAVE_SIM
 #define GLZ_GLOBAL
-#define GLZ_SIX_PER_CU
+#define GLZ_SEVEN_PER_CU
 #else
 #define GLZ_GLOBAL __attribute__((address_space(1)))
-#define GLZ_SIX_PER_CU __attribute__((amdgpu_waves_per_eu(6, 6))) /* 80 VGPRs */
+#define GLZ_SEVEN_PER_CU __attribute__((amdgpu_waves_per_eu(7, 7))) /* 72 VGPRs */
 #endif
 typedef uint32_t glz_u32x4 __attribute__((vector_size(16)));
 typedef glz_u32x4 glz_u32x4_u __attribute__((aligned(4))); /* pixel-aligned only */
@@ -1611,10 +1611,10 @@ __device__ __forceinline__ void glz_parse_image(const GlzDevJob &job, const uint
 /* One workgroup per job: apply the window-table updates, write the header
  * (glz_encoder.c:264-276), parse, report the size. */
 template <int TYPE>
-/* Six workgroups per CU (80 VGPRs, a few spilled dwords): a session's parse is
- * bound by its own latency chain, so the GPU's throughput is the number of
- * sessions it holds at once. */
-__global__ void __launch_bounds__(GLZ_THREADS) GLZ_SIX_PER_CU
+/* Seven workgroups per CU (72 VGPRs with some dwords spilled, 21 KB of LDS each):
+ * a session's parse is bound by its own latency chain, so the GPU's throughput
+ * is the number of sessions it holds at once. */
+__global__ void __launch_bounds__(GLZ_THREADS) GLZ_SEVEN_PER_CU
 glz_parse_kernel(const GlzDevJob *__restrict__ jobs, const uint32_t *__restrict__ u32_pool,
                  const GlzDevSegUpdate *__restrict__ upd_pool)
 {
