@@ -1118,6 +1118,7 @@ jpeg_finish_kernel(const JpegDevJob *jobs)
 
         const uint64_t j0 = (uint64_t)chunk * JPEG_CHUNK_BYTES + (uint64_t)tid * 16;
         uint32_t w4[4] = {0, 0, 0, 0};
+        uint32_t ffw[4] = {0, 0, 0, 0}; /* 0x80 in every byte that is a real 0xff */
         int ff = 0, n = 0;
         if (j0 < nbytes) {
             const uint4 v = *(const uint4 *)(job.scan_buf + j0);
@@ -1126,26 +1127,45 @@ jpeg_finish_kernel(const JpegDevJob *jobs)
             w4[2] = v.z;
             w4[3] = v.w;
             n = (int)(nbytes - j0 < 16 ? nbytes - j0 : 16);
-            for (int k = 0; k < n; k++) {
-                if (((w4[k >> 2] >> (8 * (k & 3))) & 0xff) == 0xff) {
-                    ff++;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                /* bytes equal to 0xff among the real ones: the zero bytes of the complement */
+                const int nb = n - 4 * i;
+                const uint32_t c = ~w4[i];
+                uint32_t z = ~(((c & 0x7f7f7f7fu) + 0x7f7f7f7fu) | c | 0x7f7f7f7fu);
+                if (nb < 4) {
+                    z = nb <= 0 ? 0u : z & (0xffffffffu >> (32 - 8 * nb));
                 }
+                ffw[i] = z;
+                ff += __popc(z);
             }
         }
         int dummy = 0;
         const int ff_lane = jpeg_block_scan(ff, wave_sums, tid, &dummy);
         uint64_t pos = (uint64_t)job.hdr_len + j0 + (uint64_t)ff_before + (uint64_t)ff_lane;
-        for (int k = 0; k < n; k++) {
-            const uint32_t b = (w4[k >> 2] >> (8 * (k & 3))) & 0xff;
-            if (pos < job.out_cap) {
-                job.out[pos] = (uint8_t)b;
+        /* a word without 0xff goes out whole (the address need not be aligned), the
+         * others and the tail byte by byte with their stuffing */
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int nb = n - 4 * i;
+            if (nb >= 4 && ffw[i] == 0 && pos + 4 <= job.out_cap) {
+                const uint32_t w = w4[i];
+                __builtin_memcpy(job.out + pos, &w, 4);
+                pos += 4;
+                continue;
             }
-            pos++;
-            if (b == 0xff) {
+            for (int k = 0; k < 4 && k < nb; k++) {
+                const uint32_t b = (w4[i] >> (8 * k)) & 0xff;
                 if (pos < job.out_cap) {
-                    job.out[pos] = 0;
+                    job.out[pos] = (uint8_t)b;
                 }
                 pos++;
+                if (b == 0xff) {
+                    if (pos < job.out_cap) {
+                        job.out[pos] = 0;
+                    }
+                    pos++;
+                }
             }
         }
     }
