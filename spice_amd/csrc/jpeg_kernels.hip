@@ -924,26 +924,49 @@ jpeg_strip_kernel(const JpegDevJob *jobs, const uint32_t *huff)
     jpeg_strip_body<IFAST>(job, huff, group);
 }
 
-/* Exclusive scan of strip_bits into strip_bitoff (64-bit), one workgroup per job. */
+/* Exclusive scan of strip_bits into strip_bitoff (64-bit), one workgroup per job:
+ * every lane sums a run of consecutive strips, the runs' sums are scanned once
+ * across the workgroup, and every lane walks its run again to write the offsets. */
 __global__ void __launch_bounds__(JT)
 jpeg_offsets_kernel(const JpegDevJob *jobs)
 {
-    __shared__ int wave_sums[JT / 64];
+    __shared__ uint64_t wave_tot[JT / 64];
     const JpegDevJob &job = jobs[blockIdx.x];
-    const int tid = (int)threadIdx.x;
-    uint64_t carry = 0;
-    for (int base = 0; base < job.nstrips; base += JT) {
-        const int i = base + tid;
-        const int v = i < job.nstrips ? (int)job.strip_bits[i] : 0;
-        int total = 0;
-        const int excl = jpeg_block_scan(v, wave_sums, tid, &total);
-        if (i < job.nstrips) {
-            job.strip_bitoff[i] = carry + (uint64_t)excl;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (job.nstrips + JT - 1) / JT;
+    const int i0 = min(tid * per, job.nstrips), i1 = min(i0 + per, job.nstrips);
+    uint64_t mine = 0;
+    for (int i = i0; i < i1; i++) {
+        mine += job.strip_bits[i];
+    }
+    uint64_t inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)inc, d);
+        const uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(inc >> 32), d);
+        if (lane >= d) {
+            inc += ((uint64_t)hi << 32) | lo;
         }
-        carry += (uint64_t)total;
+    }
+    if (lane == 63) {
+        wave_tot[wave] = inc;
+    }
+    __syncthreads();
+    uint64_t base = 0, total = 0;
+    for (int k = 0; k < JT / 64; k++) {
+        const uint64_t t = wave_tot[k];
+        if (k < wave) {
+            base += t;
+        }
+        total += t;
+    }
+    uint64_t off = base + inc - mine;
+    for (int i = i0; i < i1; i++) {
+        job.strip_bitoff[i] = off;
+        off += job.strip_bits[i];
     }
     if (tid == 0) {
-        job.strip_bitoff[job.nstrips] = carry;
+        job.strip_bitoff[job.nstrips] = total;
     }
 }
 
