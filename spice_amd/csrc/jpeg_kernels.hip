@@ -1209,13 +1209,11 @@ void jpeg_launch(const JpegDevJob *jobs, int njobs, int max_groups, bool any_isl
         hipLaunchKernelGGL(jpeg_strip_kernel<true>, grid, dim3(JT), 0, stream, jobs, huff);
         spicegpu::timing_end(t, stream);
     }
-    t = spicegpu::timing_begin("jpeg_offsets_kernel", stream);
+    /* the three bit-stream kernels share one pair of timing events: an event
+     * between two launches costs about as much as the offsets kernel itself */
+    t = spicegpu::timing_begin("jpeg_bitstream_kernels", stream);
     hipLaunchKernelGGL(jpeg_offsets_kernel, dim3((unsigned)njobs), dim3(JT), 0, stream, jobs);
-    spicegpu::timing_end(t, stream);
-    t = spicegpu::timing_begin("jpeg_gather_kernel", stream);
     hipLaunchKernelGGL(jpeg_gather_kernel, dim3(64, (unsigned)njobs), dim3(JT), 0, stream, jobs);
-    spicegpu::timing_end(t, stream);
-    t = spicegpu::timing_begin("jpeg_finish_kernel", stream);
     hipLaunchKernelGGL(jpeg_finish_kernel, dim3(64, (unsigned)njobs), dim3(JT), 0, stream, jobs);
     spicegpu::timing_end(t, stream);
 }

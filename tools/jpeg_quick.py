@@ -24,10 +24,10 @@ try:
     B.jpeg_encode_batch(gpu,items)
 except Exception as e:
     print('first batch', e)
-gpu.L.spice_gpu_timing_enable(1); gpu.L.spice_gpu_timing_reset()
+gpu.L.spice_gpu_timing_enable(0 if os.environ.get('NOTIMING') else 1); gpu.L.spice_gpu_timing_reset()
 t0=time.time()
-for _ in range(5):
+for _ in range(20):
     try: B.jpeg_encode_batch(gpu,items)
     except Exception as e: pass
-dt=(time.time()-t0)/5
+dt=(time.time()-t0)/20
 print(lib, 'ms/batch %.3f'%(dt*1e3), {k:round(v[1]/max(1,v[0]),3) for k,v in gpu.kernel_times().items()})
