@@ -224,16 +224,22 @@ class MjpegWorkload:
         self.outs = [gpu.malloc(self.cap) for _ in range(self.F)]
         self.setup_s = time.time() - t0
         self.k = 0
+        self.plan = None
         self.units_per_step = self.F * W2160 * H2160
 
     def step(self):
-        B = self.B
-        items = [dict(pixels=self.dev_frames[(f + self.k) % self.pool], format=B.BITMAP_FMT_32BIT,
-                      width=W2160, height=H2160, stride=W2160 * 4, quality=70, dct=B.DCT_IFAST,
-                      out=self.outs[f], out_capacity=self.cap) for f in range(self.F)]
-        sizes = B.jpeg_encode_batch(self.gpu, items)
+        # the job array is built once; a step hands every stream its next frame
+        if self.plan is None:
+            B = self.B
+            self.plan = B.JpegBatchPlan(self.gpu, [
+                dict(pixels=self.dev_frames[f % self.pool], format=B.BITMAP_FMT_32BIT,
+                     width=W2160, height=H2160, stride=W2160 * 4, quality=70, dct=B.DCT_IFAST,
+                     out=self.outs[f], out_capacity=self.cap) for f in range(self.F)])
+            self.step_pixels = [np.array([self.dev_frames[(f + k) % self.pool] for f in range(self.F)],
+                                         dtype=np.uint64) for k in range(self.pool)]
+        sizes = self.plan.run(self.step_pixels[self.k % self.pool])
         self.k += 1
-        self.last_out = int(sum(sizes))
+        self.last_out = int(sizes.sum())
         return self.last_out
 
     def config(self, args):

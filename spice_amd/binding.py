@@ -740,6 +740,35 @@ def jpeg_encode_batch(gpu, items):
     return [jobs[j].out_size for j in range(n)]
 
 
+class JpegBatchPlan:
+    """A device-resident JPEG batch that is submitted again and again (a set of
+    video streams): geometry, quality and output buffers stay, only the frames'
+    device pointers change.  Saves rebuilding the job array per call."""
+
+    def __init__(self, gpu, items):
+        self.gpu, self.n = gpu, len(items)
+        self.jobs = (SpiceGpuJpegJob * self.n)()
+        for j, it in enumerate(items):
+            job = self.jobs[j]
+            job.pixels, job.format = it["pixels"], it["format"]
+            job.width, job.height, job.stride = it["width"], it["height"], it["stride"]
+            job.quality, job.dct = it["quality"], it["dct"]
+            job.out, job.out_capacity = it["out"], it["out_capacity"]
+        view = lambda field, dt: np.ndarray((self.n,), dtype=dt, buffer=self.jobs, offset=field.offset,
+                                            strides=(C.sizeof(SpiceGpuJpegJob),))
+        self._pixels = view(SpiceGpuJpegJob.pixels, np.uint64)
+        self._sizes = view(SpiceGpuJpegJob.out_size, np.int32)
+
+    def run(self, pixels=None):
+        """pixels: every job's frame (device pointers, in job order).  Returns the
+        JFIF sizes (numpy int32, one per job)."""
+        if pixels is not None:
+            self._pixels[:] = pixels
+        if self.gpu.L.spice_gpu_jpeg_encode_batch(self.jobs, self.n) != 0:
+            raise SpiceGpuError("jpeg batch: " + self.gpu.last_error())
+        return self._sizes.copy()
+
+
 def graduality_batch(gpu, items):
     """Device-resident bitmaps; items are dicts with format, width, chunks (list of
     (device pointer, rows)).  Returns a list of (level, score, samples, score_quarters)."""

@@ -157,3 +157,32 @@ def test_gpu_video_frames_match_oracle(gpu, oracle):
     for it, got in zip(items, batch_encode(gpu, items)):
         want = oracle.jpeg_encode(it[0], it[1], it[2], it[0].shape[1], oracle.FMT_32BIT, it[4], it[5])
         assert_same_stream(want, got, "video frame")
+
+
+def run_batch_plan(dev, oracle):
+    """A prebuilt batch submitted twice with the frames swapped between the jobs."""
+    w, h = 96, 48
+    ims = [frames.golden_image(w, h, "desktop", s) for s in (1, 2)]
+    px = [im.reshape(h, w * 4) for im in ims]
+    want = [oracle.jpeg_encode(p, w, h, w * 4, 8, 70, B.DCT_IFAST) for p in px]
+    d_px = [dev.to_device(p) for p in px]
+    cap = dev.L.spice_gpu_jpeg_out_bound(w, h)
+    d_out = [dev.malloc(cap) for _ in px]
+    plan = B.JpegBatchPlan(dev, [dict(pixels=d_px[k], format=B.BITMAP_FMT_32BIT, width=w, height=h,
+                                      stride=w * 4, quality=70, dct=B.DCT_IFAST, out=d_out[k],
+                                      out_capacity=cap) for k in range(2)])
+    for order in ((0, 1), (1, 0), (1, 1)):
+        sizes = plan.run(np.array([d_px[k] for k in order], dtype=np.uint64))
+        for j, k in enumerate(order):
+            assert_same_stream(want[k], dev.download(d_out[j], int(sizes[j])), "order %s job %d" % (order, j))
+    for p in d_px + d_out:
+        dev.free(p)
+
+
+def test_sim_batch_plan(sim, oracle):
+    run_batch_plan(sim, oracle)
+
+
+@pytest.mark.gpu
+def test_gpu_batch_plan(gpu, oracle):
+    run_batch_plan(gpu, oracle)
