@@ -305,9 +305,14 @@ typedef struct SpiceGpuGlzJob {
 /* Bytes the output buffer of a job must hold in the worst case. */
 size_t spice_gpu_glz_out_bound(LzImageType type, int width, int height);
 
-/* Encodes njobs images, at most one per dictionary, in one pass: one parse
- * launch with a 256-lane workgroup per job, and a copy of the rows into each
- * dictionary's window in device memory.  An image of one chunk is parsed where
+/* Encodes njobs images in one call: a parse launch with a 256-lane workgroup
+ * per job, and a copy of the rows into each dictionary's window in device
+ * memory.  Jobs that share a dictionary (the display channels of one client,
+ * server/red_worker.c:9677-9754) are encoded one after the other in the
+ * caller's job order -- the batch is cut into as many launches as the most
+ * images any one dictionary gets -- and produce exactly the streams that
+ * separate glz_encode calls in that order would.  Submit and finish must be
+ * called by the same thread, or by two threads that hand the batch over.  An image of one chunk is parsed where
  * the caller put it and its copy runs beside the parse; other images are copied
  * first.  The chunk buffers must stay valid and unchanged until the call (or
  * spice_gpu_glz_finish) returns.  Workgroups start in the order of expected
@@ -322,6 +327,9 @@ int spice_gpu_glz_encode_batch(SpiceGpuGlzJob *jobs, int njobs);
  * and completes the host bookkeeping (post-encode window maintenance). */
 int spice_gpu_glz_submit(SpiceGpuGlzJob *jobs, int njobs);
 int spice_gpu_glz_finish(SpiceGpuGlzJob *jobs, int njobs);
+/* Host time the last batch's submit + finish took, the wait for the device
+ * excluded: window bookkeeping, job staging, result hand-out. */
+uint64_t spice_gpu_glz_last_batch_host_ns(void);
 
 enum { SPICE_GPU_DCT_ISLOW = 0, SPICE_GPU_DCT_IFAST = 1 };
 

@@ -165,7 +165,7 @@ EXPORTS = [
     "spice_gpu_mjpeg_rate_feed",
     "jpeg_encoder_create", "jpeg_encoder_destroy", "jpeg_encode",
     "spice_gpu_glz_out_bound", "spice_gpu_glz_encode_batch", "spice_gpu_glz_submit",
-    "spice_gpu_glz_finish", "spice_gpu_jpeg_out_bound", "spice_gpu_jpeg_encode_batch",
+    "spice_gpu_glz_finish", "spice_gpu_glz_last_batch_host_ns", "spice_gpu_jpeg_out_bound", "spice_gpu_jpeg_encode_batch",
     "spice_gpu_jpeg_submit", "spice_gpu_jpeg_finish", "spice_gpu_malloc", "spice_gpu_free",
     "spice_gpu_upload", "spice_gpu_download", "spice_gpu_get_stats", "spice_gpu_reset_stats",
     "spice_gpu_timing_enable", "spice_gpu_timing_reset", "spice_gpu_timing_read",
@@ -232,6 +232,7 @@ class SpiceGpu:
         for n in ("spice_gpu_glz_encode_batch", "spice_gpu_glz_submit", "spice_gpu_glz_finish"):
             getattr(L, n).restype = i
             getattr(L, n).argtypes = [C.POINTER(SpiceGpuGlzJob), i]
+        L.spice_gpu_glz_last_batch_host_ns.restype = C.c_uint64
         L.spice_gpu_jpeg_out_bound.restype = C.c_size_t
         L.spice_gpu_jpeg_out_bound.argtypes = [i, i]
         for n in ("spice_gpu_jpeg_encode_batch", "spice_gpu_jpeg_submit", "spice_gpu_jpeg_finish"):
@@ -652,10 +653,12 @@ class JpegEncoder:
         return self.out.gather(n)
 
 
-def glz_encode_batch(gpu, items, split=False):
+def glz_encode_batch(gpu, items, split=False, raise_on_error=True):
     """Device-resident batch: items are dicts with encoder (GlzEncoder), type,
     width, height, stride, top_down, chunks (device pointers), chunk_rows, out
-    (device pointer), out_capacity.  Returns the list of sizes."""
+    (device pointer), out_capacity.  Jobs that share a dictionary are encoded in
+    the order given.  Returns (sizes, window images); with raise_on_error=False a
+    failed batch returns too, the failed jobs with a size <= 0."""
     n = len(items)
     jobs = (SpiceGpuGlzJob * n)()
     keep = []
@@ -679,7 +682,7 @@ def glz_encode_batch(gpu, items, split=False):
             rc = gpu.L.spice_gpu_glz_finish(jobs, n)
     else:
         rc = gpu.L.spice_gpu_glz_encode_batch(jobs, n)
-    if rc != 0:
+    if rc != 0 and raise_on_error:
         raise SpiceGpuError("glz batch: " + gpu.last_error())
     return [jobs[j].out_size for j in range(n)], [jobs[j].dict_image for j in range(n)]
 
@@ -812,7 +815,9 @@ class ImageCompressor:
     the choice of codec, then red_glz_compress_image (:6003-6102, with the optional
     zlib wrap) or red_jpeg_compress_image (:6182-6279).  QUIC, LZ and the LZ-coded
     alpha plane of JPEG_ALPHA belong to spice-common, which this library does not
-    replace: for those the result names the codec and carries no data.
+    replace: for those the result names the codec, carries no data and is marked
+    "delegate" -- the caller runs that encoder itself or sends the bitmap raw; it is
+    never to be taken for a compressed image.
 
     compress() returns None where the reference returns FALSE (the bitmap goes out
     raw), else a dict with "type" (the SPICE_IMAGE_TYPE_* name), "data" and, for
@@ -865,18 +870,19 @@ class ImageCompressor:
         if codec == CODEC_ERROR:
             raise SpiceGpuError("invalid image compression type %r" % (self.image_compression,))
         if codec == CODEC_QUIC:
-            return {"type": "QUIC", "data": None}
+            return {"type": "QUIC", "data": None, "delegate": True}
         if codec == CODEC_LZ:
-            return {"type": "LZ_RGB", "data": None}
+            return {"type": "LZ_RGB", "data": None, "delegate": True}
         if codec == CODEC_JPEG:
             if fmt not in self.FMT_TO_JPEG:
                 return None                          # :6218-6219
+            if fmt == BITMAP_FMT_RGBA:
+                # the JPEG is followed by lz_encode(XXXA) of the alpha plane in one chain (:6281-6300)
+                return {"type": "JPEG_ALPHA", "data": None, "delegate": True}
             data = self.jpeg.encode(self.jpeg_quality, self.FMT_TO_JPEG[fmt], x, y, stride, chunks,
                                     top_down=top_down)
             if len(data) > y * stride:
                 return None                          # :6263-6266
-            if fmt == BITMAP_FMT_RGBA:
-                return {"type": "JPEG_ALPHA", "data": None, "jpeg": data}
             return {"type": "JPEG", "data": data, "is_lossy": True}
         data, image = self.glz.encode(self.FMT_TO_LZ[fmt], x, y, stride, chunks, top_down=top_down,
                                       usr_context=usr_context)

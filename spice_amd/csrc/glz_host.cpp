@@ -17,6 +17,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <memory>
 #include <mutex>
 #include <vector>
 
@@ -315,7 +316,10 @@ bool dict_reset(Dict *d)
     d->ring_head = d->ring_tail = 0;
     d->ring_wrapped = false;
     hipStream_t st = stream();
-    std::lock_guard<std::mutex> dev(device_mutex());
+    GateHold dev("glz dictionary reset");
+    if (!dev.ok) {
+        return false;
+    }
     return check(hipMemsetAsync(d->d_htab, 0, sizeof(uint2) * (size_t)GLZ_HASH_SIZE, st), "memset htab") &&
            check(hipMemsetAsync(d->d_segs, 0, sizeof(GlzDevSeg) * (size_t)d->d_segs_cap, st), "memset segs") &&
            check(hipStreamSynchronize(st), "sync");
@@ -469,6 +473,16 @@ struct Prepared {
     std::vector<GlzDevSegUpdate> updates;
     std::vector<GlzCopyDesc> copies; /* src -> arena, in segment order */
     uint64_t raw_bytes = 0;
+
+    void reset()
+    {
+        enc = nullptr;
+        image = nullptr;
+        seg_list.clear();
+        updates.clear();
+        copies.clear();
+        raw_bytes = 0;
+    }
 };
 
 const char *validate(LzImageType type, int width, int height, int stride)
@@ -595,6 +609,9 @@ const char *prepare(Encoder *enc, LzImageType type, int width, int height, int t
     }
 
     if (!ensure_dev_segs(d)) {
+        /* the image is in the window already: it must never be referenced */
+        im->alive = false;
+        post_encode(d, enc->id);
         return "device segment table allocation failed\n";
     }
     for (uint32_t s : d->dirty) {
@@ -633,15 +650,58 @@ const char *prepare(Encoder *enc, LzImageType type, int width, int height, int t
     return nullptr;
 }
 
-/* Batch in flight between submit and finish (guarded by device_mutex). */
-struct Flight {
-    std::vector<Prepared> jobs;
-    std::vector<std::unique_lock<std::recursive_mutex>> dict_locks;
-    std::unique_lock<std::mutex> dev_lock;
+/* An image that was added to its window but whose stream the client will never
+ * receive (the launch failed, the device reported an error, the output did not
+ * fit): it stays in the window as a dead image, like one removed with
+ * glz_enc_dictionary_remove_image, so that no later image refers to it.  In
+ * the reference this situation is fatal (usr->error is spice_critical,
+ * server/red_worker.c:5578-5591). */
+void kill_image(Dict *d, HostImage *im)
+{
+    if (im && im->alive) {
+        im->alive = false;
+        mark_image_dirty(d, im);
+    }
+}
+
+/* A prepared job that will not be launched: its segment updates go back on the
+ * dictionary's list, its image dies, its encoder lets go of the window. */
+void abandon(Prepared &p)
+{
+    if (!p.enc) {
+        return;
+    }
+    Dict *d = p.enc->dict;
+    for (const GlzDevSegUpdate &u : p.updates) {
+        d->dirty.push_back(u.index);
+    }
+    kill_image(d, p.image);
+    post_encode(d, p.enc->id);
+    p.reset();
+}
+
+/* Jobs of a batch that may run side by side: at most one per dictionary.  A
+ * batch with several images for one dictionary (the display channels of one
+ * client share theirs, server/red_worker.c:9677-9754) is cut into levels, the
+ * k-th image of every dictionary in level k; levels run one after the other on
+ * the library's stream, so each dictionary sees its images in the caller's
+ * order, exactly as if they had been encoded by separate calls. */
+struct Level {
+    std::vector<int> idx;       /* the caller's job numbers, ascending */
+    std::vector<Prepared> jobs; /* same order */
     Staging staging;
     size_t results_off = 0;
+};
+
+/* Batch in flight between submit and finish; the device gate is held meanwhile. */
+struct Flight {
+    std::vector<std::unique_ptr<Level>> levels; /* kept between batches for their buffers */
+    size_t nlevels = 0;
+    int njobs = 0;
+    std::vector<std::unique_lock<std::recursive_mutex>> dict_locks;
     bool active = false;
     uint64_t t0 = 0;
+    uint64_t host_ns = 0; /* host time of the last submit + finish, waiting excluded */
 };
 Flight g_flight;
 
@@ -649,13 +709,13 @@ Flight g_flight;
  * them and enqueues copy + parse.  copy_on_device: the chunk sources are
  * device pointers (batch path); otherwise the caller has already enqueued
  * host-to-arena copies on the stream. */
-bool launch(std::vector<Prepared> &jobs, Staging &st, size_t *results_off, bool copy_on_device)
+bool launch(Prepared *jobs, size_t n, Staging &st, size_t *results_off, bool copy_on_device)
 {
-    size_t n = jobs.size();
     size_t off_jobs = 0;
     size_t off_u32 = off_jobs + sizeof(GlzDevJob) * n;
     size_t n_u32 = 0, n_upd = 0, n_copy = 0;
-    for (Prepared &p : jobs) {
+    for (size_t j = 0; j < n; j++) {
+        const Prepared &p = jobs[j];
         n_u32 += p.seg_list.size();
         n_upd += p.updates.size();
         n_copy += p.copies.size();
@@ -709,8 +769,8 @@ bool launch(std::vector<Prepared> &jobs, Staging &st, size_t *results_off, bool 
      * into the arenas run on the side stream beside the parse; stream() waits
      * for them at the end, so whoever synchronises it has both. */
     bool beside = copy_on_device && n_copy != 0;
-    for (Prepared &p : jobs) {
-        beside = beside && p.dev.own_src != nullptr;
+    for (size_t j = 0; j < n; j++) {
+        beside = beside && jobs[j].dev.own_src != nullptr;
     }
     uint64_t per_block = 256ull * 16 * 8; /* 8 vectors per lane */
     unsigned blocks = (unsigned)((max_copy + per_block - 1) / per_block);
@@ -722,8 +782,8 @@ bool launch(std::vector<Prepared> &jobs, Staging &st, size_t *results_off, bool 
         return false;
     }
     unsigned type_mask = 0;
-    for (Prepared &p : jobs) {
-        type_mask |= 1u << p.dev.type;
+    for (size_t j = 0; j < n; j++) {
+        type_mask |= 1u << jobs[j].dev.type;
     }
     glz_launch_parse((const GlzDevJob *)(st.dev + off_jobs), (int)n, type_mask,
                      (const uint32_t *)(st.dev + off_u32),
@@ -957,7 +1017,11 @@ int glz_encode(GlzEncoderContext *opaque_encoder, LzImageType type, int width, i
     }
 
     std::lock_guard<std::recursive_mutex> dict_lock(d->lock);
-    std::lock_guard<std::mutex> dev_lock(device_mutex());
+    GateHold dev_lock("glz_encode");
+    if (!dev_lock.ok) {
+        usr_error(enc->usr, "a batch of this thread is in flight\n");
+        return 0;
+    }
 
     size_t bound = spice_gpu_glz_out_bound(type, width, height);
     if (!enc->out.reserve(bound) || !enc->bounce.reserve(bound)) {
@@ -982,13 +1046,22 @@ int glz_encode(GlzEncoderContext *opaque_encoder, LzImageType type, int width, i
     for (const GlzCopyDesc &c : jobs[0].copies) {
         ok = ok && check(hipMemcpyAsync(c.dst, c.src, c.bytes, hipMemcpyHostToDevice, s), "upload rows");
     }
-    ok = ok && launch(jobs, staging, &res_off, false);
+    ok = ok && launch(jobs.data(), 1, staging, &res_off, false);
     ok = ok && check(hipStreamSynchronize(s), "glz sync");
     int32_t size = ok ? *(int32_t *)(staging.host + res_off) : 0;
     if (ok && size > 0) {
         ok = check(hipMemcpyAsync(enc->bounce.ptr, enc->out.ptr, (size_t)size,
                                   hipMemcpyDeviceToHost, s), "download stream") &&
              check(hipStreamSynchronize(s), "glz sync");
+    }
+    if (!ok) {
+        hipStreamSynchronize(s); /* nothing of this image may still be running */
+    }
+    if (!ok || size <= 0) {
+        kill_image(d, jobs[0].image);
+        if (o_enc_dict_context) {
+            *o_enc_dict_context = nullptr;
+        }
     }
     post_encode(d, enc->id);
     if (!ok || size <= 0) {
@@ -1032,109 +1105,194 @@ int spice_gpu_glz_submit(SpiceGpuGlzJob *jobs, int njobs)
         set_error("glz batch: no jobs");
         return -1;
     }
-    Flight &f = g_flight;
-    /* lock order everywhere: dictionaries, then the device */
-    std::vector<std::unique_lock<std::recursive_mutex>> dict_locks;
-    for (int j = 0; j < njobs; j++) {
-        Encoder *enc = (Encoder *)jobs[j].encoder;
-        if (!enc) {
-            set_error("glz batch job %d: null encoder", j);
-            return -1;
-        }
-        for (int k = 0; k < j; k++) {
-            if (((Encoder *)jobs[k].encoder)->dict == enc->dict) {
-                set_error("glz batch job %d: two jobs of one batch share a dictionary", j);
-                return -1;
-            }
-        }
-        dict_locks.emplace_back(enc->dict->lock);
-    }
-    std::unique_lock<std::mutex> dev_lock(device_mutex());
-    if (f.active) {
-        set_error("glz batch: a batch is already in flight");
-        return -1;
-    }
-    f.jobs.clear();
-    f.jobs.resize((size_t)njobs);
-    f.dict_locks = std::move(dict_locks);
-    f.t0 = now_ns();
-
+    const uint64_t t_in = now_ns();
+    /* everything that can be checked without touching a window is checked first:
+     * a bad job must not leave other jobs' images half added */
+    std::vector<Dict *> dicts((size_t)njobs);
     for (int j = 0; j < njobs; j++) {
         SpiceGpuGlzJob &job = jobs[j];
         Encoder *enc = (Encoder *)job.encoder;
         job.out_size = -1;
         job.dict_image = nullptr;
+        if (!enc) {
+            set_error("glz batch job %d: null encoder", j);
+            return -1;
+        }
         const char *err = validate(job.type, job.width, job.height, job.stride);
+        if (!err && (job.nchunks <= 0 || !job.chunk_ptrs || !job.chunk_rows || !job.out)) {
+            err = "no chunks or no output buffer\n";
+        }
         if (!err) {
-            std::vector<Chunk> chunks;
+            uint64_t rows = 0;
             for (int c = 0; c < job.nchunks; c++) {
-                chunks.push_back(Chunk{(const uint8_t *)job.chunk_ptrs[c], job.chunk_rows[c]});
+                rows += job.chunk_rows[c];
+                if (!job.chunk_ptrs[c]) {
+                    err = "null chunk\n";
+                }
             }
-            err = prepare(enc, job.type, job.width, job.height, job.top_down, job.stride, chunks,
-                          job.usr_context, (uint8_t *)job.out, job.out_capacity, true,
-                          &f.jobs[(size_t)j]);
-            if (!err) {
-                job.dict_image = (GlzEncDictImageContext *)f.jobs[(size_t)j].image;
+            const int64_t px = (int64_t)job.height * job.stride / kRgbBytesPerPixel[job.type];
+            if (rows < (uint64_t)job.height) {
+                err = "more lines failed\n"; /* glz_encoder_dictionary.c:497-501,517-520 */
+            } else if (px > (int64_t)enc->dict->size_limit) {
+                err = "image is bigger than window\n"; /* glz_encoder_dictionary.c:397-399 */
             }
         }
         if (err) {
-            /* jobs prepared so far have changed their windows; close them properly */
             set_error("glz batch job %d: %s", j, err);
-            for (int k = 0; k < j; k++) {
-                Encoder *e = (Encoder *)jobs[k].encoder;
-                post_encode(e->dict, e->id);
-            }
-            f.dict_locks.clear();
-            f.jobs.clear();
             return -1;
         }
+        dicts[(size_t)j] = enc->dict;
     }
-    if (!launch(f.jobs, f.staging, &f.results_off, true)) {
-        for (int k = 0; k < njobs; k++) {
-            Encoder *e = (Encoder *)jobs[k].encoder;
-            post_encode(e->dict, e->id);
-        }
-        f.dict_locks.clear();
-        f.jobs.clear();
+    /* the distinct dictionaries, in address order (two batches that name the same
+     * dictionaries in different orders must not wait for each other) */
+    std::vector<Dict *> distinct(dicts);
+    std::sort(distinct.begin(), distinct.end());
+    distinct.erase(std::unique(distinct.begin(), distinct.end()), distinct.end());
+    /* level of a job = how many earlier jobs of the batch use its dictionary */
+    std::vector<uint32_t> seen(distinct.size(), 0);
+    std::vector<uint32_t> level_of((size_t)njobs);
+    size_t nlevels = 0;
+    for (int j = 0; j < njobs; j++) {
+        const size_t k = (size_t)(std::lower_bound(distinct.begin(), distinct.end(), dicts[(size_t)j]) -
+                                  distinct.begin());
+        level_of[(size_t)j] = seen[k]++;
+        nlevels = seen[k] > nlevels ? seen[k] : nlevels;
+    }
+    /* lock order everywhere: dictionaries, then the device */
+    std::vector<std::unique_lock<std::recursive_mutex>> dict_locks;
+    dict_locks.reserve(distinct.size());
+    for (Dict *d : distinct) {
+        dict_locks.emplace_back(d->lock);
+    }
+    if (!device_gate().acquire("glz batch")) {
         return -1;
     }
+    Flight &f = g_flight;
+    while (f.levels.size() < nlevels) {
+        f.levels.emplace_back(new Level());
+    }
+    for (size_t l = 0; l < nlevels; l++) {
+        f.levels[l]->idx.clear();
+    }
+    for (int j = 0; j < njobs; j++) {
+        f.levels[level_of[(size_t)j]]->idx.push_back(j);
+    }
+    f.nlevels = nlevels;
+    f.njobs = njobs;
+    f.t0 = t_in;
+
+    bool ok = true;
+    std::vector<Chunk> chunks;
+    for (size_t l = 0; l < nlevels && ok; l++) {
+        Level &lv = *f.levels[l];
+        if (lv.jobs.size() < lv.idx.size()) {
+            lv.jobs.resize(lv.idx.size());
+        }
+        size_t done = 0;
+        for (; done < lv.idx.size() && ok; done++) {
+            const int j = lv.idx[done];
+            SpiceGpuGlzJob &job = jobs[j];
+            Prepared &p = lv.jobs[done];
+            p.reset();
+            chunks.clear();
+            for (int c = 0; c < job.nchunks; c++) {
+                chunks.push_back(Chunk{(const uint8_t *)job.chunk_ptrs[c], job.chunk_rows[c]});
+            }
+            const char *err = prepare((Encoder *)job.encoder, job.type, job.width, job.height,
+                                      job.top_down, job.stride, chunks, job.usr_context,
+                                      (uint8_t *)job.out, job.out_capacity, true, &p);
+            if (err) {
+                set_error("glz batch job %d: %s", j, err);
+                p.reset();
+                ok = false;
+                break;
+            }
+            job.dict_image = (GlzEncDictImageContext *)p.image;
+        }
+        if (ok) {
+            ok = launch(lv.jobs.data(), lv.idx.size(), lv.staging, &lv.results_off, true);
+            done = lv.idx.size();
+        }
+        if (ok) {
+            /* glz_dictionary_post_encode: the window bookkeeping does not depend on
+             * what the device produces, and the next level's images must see it */
+            for (size_t k = 0; k < lv.idx.size(); k++) {
+                post_encode(lv.jobs[k].enc->dict, lv.jobs[k].enc->id);
+            }
+        } else {
+            /* nothing of this level runs (a failed launch is waited for below) */
+            for (size_t k = 0; k < done && k < lv.jobs.size(); k++) {
+                abandon(lv.jobs[k]);
+            }
+            /* images of the levels already enqueued: their streams are never
+             * handed out, so they die too */
+            hipStreamSynchronize(stream());
+            for (size_t e = 0; e < l; e++) {
+                Level &el = *f.levels[e];
+                for (size_t k = 0; k < el.idx.size(); k++) {
+                    kill_image(el.jobs[k].enc->dict, el.jobs[k].image);
+                }
+            }
+        }
+    }
+    if (!ok) {
+        for (int j = 0; j < njobs; j++) {
+            jobs[j].dict_image = nullptr;
+        }
+        f.nlevels = 0;
+        device_gate().release();
+        return -1;
+    }
+    f.dict_locks = std::move(dict_locks);
     f.active = true;
-    f.dev_lock = std::move(dev_lock);
+    f.host_ns = now_ns() - t_in;
     return 0;
 }
 
 int spice_gpu_glz_finish(SpiceGpuGlzJob *jobs, int njobs)
 {
     Flight &f = g_flight;
-    if (!f.active || (size_t)njobs != f.jobs.size()) {
+    if (!f.active || njobs != f.njobs) {
         set_error("glz batch: finish without a matching submit");
         return -1;
     }
     bool ok = check(hipStreamSynchronize(stream()), "glz batch sync");
-    const int32_t *res = (const int32_t *)(f.staging.host + f.results_off);
+    const uint64_t t_sync = now_ns();
     int rc = ok ? 0 : -1;
-    uint64_t dt = now_ns() - f.t0;
-    for (int j = 0; j < njobs; j++) {
-        Encoder *e = (Encoder *)jobs[j].encoder;
-        jobs[j].out_size = ok ? res[j] : -1;
-        post_encode(e->dict, e->id);
-        if (jobs[j].out_size <= 0) {
-            if (ok) {
-                set_error("glz batch job %d: device error %d", j, jobs[j].out_size);
+    uint64_t dt = t_sync - f.t0;
+    for (size_t l = 0; l < f.nlevels; l++) {
+        Level &lv = *f.levels[l];
+        const int32_t *res = (const int32_t *)(lv.staging.host + lv.results_off);
+        for (size_t k = 0; k < lv.idx.size(); k++) {
+            const int j = lv.idx[k];
+            Prepared &p = lv.jobs[k];
+            Dict *d = p.enc->dict;
+            jobs[j].out_size = ok ? res[k] : -1;
+            if (jobs[j].out_size <= 0) {
+                if (ok) {
+                    set_error("glz batch job %d: device error %d", j, jobs[j].out_size);
+                }
+                kill_image(d, p.image);
+                jobs[j].dict_image = nullptr;
+                rc = -1;
+            } else {
+                stat_add(SPICE_GPU_STAT_GLZ, p.raw_bytes, (uint64_t)jobs[j].out_size,
+                         dt / (uint64_t)njobs);
+                d->cost_hint = (double)jobs[j].out_size / (double)p.raw_bytes;
             }
-            rc = -1;
-        } else {
-            stat_add(SPICE_GPU_STAT_GLZ, f.jobs[(size_t)j].raw_bytes, (uint64_t)jobs[j].out_size,
-                     dt / (uint64_t)njobs);
-            e->dict->cost_hint = (double)jobs[j].out_size / (double)f.jobs[(size_t)j].raw_bytes;
         }
     }
     f.dict_locks.clear();
-    f.jobs.clear();
+    f.nlevels = 0;
     f.active = false;
-    f.dev_lock.unlock();
-    f.dev_lock = std::unique_lock<std::mutex>();
+    f.host_ns += now_ns() - t_sync;
+    device_gate().release();
     return rc;
+}
+
+uint64_t spice_gpu_glz_last_batch_host_ns(void)
+{
+    return g_flight.host_ns;
 }
 
 int spice_gpu_glz_encode_batch(SpiceGpuGlzJob *jobs, int njobs)

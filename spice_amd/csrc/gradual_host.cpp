@@ -143,7 +143,10 @@ int spice_gpu_graduality_batch(SpiceGpuGradualJob *jobs, int njobs)
     const size_t total = pool_off + sizeof(uint32_t) * pool.size() + 16;
     const size_t res_b = sizeof(long long) * 2 * (size_t)njobs;
 
-    std::lock_guard<std::mutex> dev_lock(device_mutex());
+    GateHold dev_lock("graduality");
+    if (!dev_lock.ok) {
+        return -1;
+    }
     if (!g_stage.reserve(total) || !g_results.reserve(res_b)) {
         return -1;
     }

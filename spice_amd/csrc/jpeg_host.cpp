@@ -219,15 +219,14 @@ bool fill_job(JpegDevJob *j, const void *pixels, int format, int width, int heig
     return true;
 }
 
-/* Library-owned device scratch for one batch (guarded by device_mutex). */
+/* Library-owned device scratch for one batch (guarded by the device gate). */
 struct JpegFlight {
     Staging staging;      /* JpegDevJob array + results */
     DevBuffer scratch;
     uint32_t *d_huff = nullptr;
     size_t results_off = 0;
     int njobs = 0;
-    bool active = false;
-    std::unique_lock<std::mutex> dev_lock;
+    bool active = false; /* between submit and finish; the gate is held meanwhile */
     uint64_t t0 = 0;
     uint64_t raw_bytes = 0;
     int stat_codec = SPICE_GPU_STAT_MJPEG;
@@ -255,7 +254,7 @@ size_t align256(size_t v)
     return (v + 255) & ~(size_t)255;
 }
 
-/* Enqueues a batch.  Caller holds device_mutex and has filled jobs[] with fill_job. */
+/* Enqueues a batch.  Caller holds the device gate and has filled jobs[] with fill_job. */
 bool submit_locked(JpegFlight &f, std::vector<JpegDevJob> &jobs)
 {
     int n = (int)jobs.size();
@@ -333,7 +332,10 @@ size_t encode_host_frame(HostPath &hp, int format, int width, int height, int qu
     size_t bytes = row * (size_t)height;
     size_t cap = (size_t)width * (size_t)height * 3 + 4096; /* far above any real frame */
     cap = cap > 0x7fff0000u ? 0x7fff0000u : cap;
-    std::lock_guard<std::mutex> dev(device_mutex());
+    GateHold dev("jpeg");
+    if (!dev.ok) {
+        return 0;
+    }
     if (!hp.d_frame.reserve(bytes + 64) || !hp.d_out.reserve(cap) || !hp.out.reserve(cap)) {
         return 0;
     }
@@ -690,13 +692,8 @@ int spice_gpu_jpeg_submit(SpiceGpuJpegJob *jobs, int njobs)
         return -1;
     }
     JpegFlight &f = g_jf;
-    std::unique_lock<std::mutex> dev_lock(device_mutex());
-    if (f.active) {
-        set_error("jpeg batch: a batch is already in flight");
-        return -1;
-    }
     std::vector<JpegDevJob> dj((size_t)njobs);
-    f.raw_bytes = 0;
+    uint64_t raw_bytes = 0;
     for (int k = 0; k < njobs; k++) {
         SpiceGpuJpegJob &j = jobs[k];
         j.out_size = -1;
@@ -705,14 +702,21 @@ int spice_gpu_jpeg_submit(SpiceGpuJpegJob *jobs, int njobs)
             set_error("jpeg batch job %d: unsupported parameters", k);
             return -1;
         }
-        f.raw_bytes += (uint64_t)j.width * (uint64_t)j.height * (uint64_t)format_bpp(j.format);
+        raw_bytes += (uint64_t)j.width * (uint64_t)j.height * (uint64_t)format_bpp(j.format);
     }
+    /* the gate stays taken until spice_gpu_jpeg_finish; a second submit from this
+     * thread is refused, one from another thread waits for the finish */
+    if (!device_gate().acquire("jpeg batch")) {
+        return -1;
+    }
+    f.raw_bytes = raw_bytes;
     f.t0 = now_ns();
     if (!submit_locked(f, dj)) {
+        hipStreamSynchronize(stream());
+        device_gate().release();
         return -1;
     }
     f.active = true;
-    f.dev_lock = std::move(dev_lock);
     return 0;
 }
 
@@ -743,8 +747,7 @@ int spice_gpu_jpeg_finish(SpiceGpuJpegJob *jobs, int njobs)
         }
     }
     f.active = false;
-    f.dev_lock.unlock();
-    f.dev_lock = std::unique_lock<std::mutex>();
+    device_gate().release();
     return rc;
 }
 

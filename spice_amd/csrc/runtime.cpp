@@ -4,17 +4,24 @@
 #include "runtime.h"
 
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <time.h>
 
+#include <condition_variable>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace spicegpu {
 
 namespace {
 std::mutex g_init_mutex;
-std::mutex g_device_mutex;
+std::mutex g_gate_mutex;
+std::condition_variable g_gate_cv;
+bool g_gate_busy = false;
+std::thread::id g_gate_owner;
+DeviceGate g_gate;
 std::mutex g_stat_mutex;
 bool g_ready = false;
 int g_device = -1;
@@ -100,9 +107,32 @@ hipEvent_t join_event()
     return g_join;
 }
 
-std::mutex &device_mutex()
+bool DeviceGate::acquire(const char *who)
 {
-    return g_device_mutex;
+    std::unique_lock<std::mutex> lk(g_gate_mutex);
+    if (g_gate_busy && g_gate_owner == std::this_thread::get_id()) {
+        set_error("%s: this thread has a batch in flight (submit without finish)", who);
+        return false;
+    }
+    g_gate_cv.wait(lk, [] { return !g_gate_busy; });
+    g_gate_busy = true;
+    g_gate_owner = std::this_thread::get_id();
+    return true;
+}
+
+void DeviceGate::release()
+{
+    {
+        std::lock_guard<std::mutex> lk(g_gate_mutex);
+        g_gate_busy = false;
+        g_gate_owner = std::thread::id();
+    }
+    g_gate_cv.notify_one();
+}
+
+DeviceGate &device_gate()
+{
+    return g_gate;
 }
 
 uint64_t now_ns()
@@ -131,8 +161,11 @@ void stat_add(int codec, uint64_t orig, uint64_t comp, uint64_t ns)
 namespace {
 struct TimedLaunch {
     int name_id;
+    int id;      /* what timing_begin returned */
+    bool closed; /* timing_end has recorded b */
     hipEvent_t a, b;
 };
+int g_time_next_id = 0;
 std::mutex g_time_mutex;
 bool g_timing = false;
 std::vector<std::string> g_time_names;
@@ -152,10 +185,16 @@ hipEvent_t take_event()
     return e;
 }
 
-/* folds finished launches into the per-name totals; the stream must be idle */
+/* folds finished launches into the per-name totals; the stream must be idle.
+ * A launch whose timing_end has not come yet stays pending. */
 void timing_collect_locked()
 {
+    std::vector<TimedLaunch> open;
     for (TimedLaunch &t : g_time_pending) {
+        if (!t.closed) {
+            open.push_back(t);
+            continue;
+        }
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
             g_time_acc[(size_t)t.name_id].launches++;
@@ -164,7 +203,7 @@ void timing_collect_locked()
         g_event_pool.push_back(t.a);
         g_event_pool.push_back(t.b);
     }
-    g_time_pending.clear();
+    g_time_pending.swap(open);
 }
 } // namespace
 
@@ -188,10 +227,11 @@ int timing_begin(const char *kernel_name, hipStream_t s)
         snprintf(t.name, sizeof(t.name), "%s", kernel_name);
         g_time_acc.push_back(t);
     }
-    TimedLaunch t{id, take_event(), take_event()};
+    TimedLaunch t{id, g_time_next_id, false, take_event(), take_event()};
+    g_time_next_id = (g_time_next_id + 1) & 0x3fffffff;
     hipEventRecord(t.a, s);
     g_time_pending.push_back(t);
-    return (int)g_time_pending.size() - 1;
+    return t.id;
 }
 
 void timing_end(int token, hipStream_t s)
@@ -200,8 +240,12 @@ void timing_end(int token, hipStream_t s)
         return;
     }
     std::lock_guard<std::mutex> lock(g_time_mutex);
-    if ((size_t)token < g_time_pending.size()) {
-        hipEventRecord(g_time_pending[(size_t)token].b, s);
+    for (size_t k = g_time_pending.size(); k-- > 0;) {
+        if (g_time_pending[k].id == token && !g_time_pending[k].closed) {
+            hipEventRecord(g_time_pending[k].b, s);
+            g_time_pending[k].closed = true;
+            break;
+        }
     }
 }
 
@@ -309,6 +353,19 @@ void spice_gpu_shutdown(void)
         hipStreamSynchronize(g_stream);
         hipStreamDestroy(g_stream);
         g_stream = nullptr;
+    }
+    if (g_side_stream) {
+        hipStreamSynchronize(g_side_stream);
+        hipStreamDestroy(g_side_stream);
+        g_side_stream = nullptr;
+    }
+    if (g_fork) {
+        hipEventDestroy(g_fork);
+        g_fork = nullptr;
+    }
+    if (g_join) {
+        hipEventDestroy(g_join);
+        g_join = nullptr;
     }
     g_ready = false;
 }

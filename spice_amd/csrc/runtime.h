@@ -27,8 +27,31 @@ hipEvent_t join_event();
 void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
 bool check(hipError_t e, const char *what);
 
-/* Serialises device work issued through the library's single stream. */
-std::mutex &device_mutex();
+/* Serialises device work issued through the library's single stream.  Unlike a
+ * mutex it may be released by another thread than the one that took it (a batch
+ * is submitted and finished by two calls), and a thread that asks for it while
+ * it holds it itself is told so instead of waiting for ever. */
+class DeviceGate {
+public:
+    /* false (with the error text set) when the calling thread already holds the gate */
+    bool acquire(const char *who);
+    void release();
+};
+DeviceGate &device_gate();
+
+/* Holds the gate for a scope; `ok` is false when it could not be taken. */
+struct GateHold {
+    bool ok;
+    explicit GateHold(const char *who) : ok(device_gate().acquire(who)) {}
+    ~GateHold()
+    {
+        if (ok) {
+            device_gate().release();
+        }
+    }
+    GateHold(const GateHold &) = delete;
+    GateHold &operator=(const GateHold &) = delete;
+};
 
 void stat_add(int codec, uint64_t orig, uint64_t comp, uint64_t ns);
 

@@ -85,7 +85,7 @@ int main(int argc, char **argv)
             }
         }
         ok = host_compress_image(dcc, &bm, h4[3], BITMAP_GRADUAL_INVALID, (uintptr_t)(1000 + b), &res);
-        if (ok && res.comp_buf) {
+        if (ok == 1 && res.comp_buf) {
             bytes = (uint8_t *)malloc(res.comp_buf_size);
             size = (uint32_t)host_gather_compressed(&res, bytes, res.comp_buf_size);
         }

@@ -417,6 +417,14 @@ static int jpeg_compress_image(HostDisplayClient *dcc, const HostBitmap *src, Ho
     default:
         return 0;
     }
+    if (has_alpha) {
+        /* JPEG_ALPHA is the JPEG followed by lz_encode(LZ_IMAGE_TYPE_XXXA) of the
+         * alpha plane in the same chain (server/red_worker.c:6281-6300); lz_encode
+         * is spice-common's, so the whole image is left to the caller rather than
+         * handed out with half its data */
+        out->type = HOST_IMAGE_TYPE_JPEG_ALPHA;
+        return HOST_COMPRESS_DELEGATE;
+    }
     j->data.bufs_tail = alloc_compress_buf(dcc);
     j->data.bufs_head = j->data.bufs_tail;
     if (!j->data.bufs_head) {
@@ -439,17 +447,8 @@ static int jpeg_compress_image(HostDisplayClient *dcc, const HostBitmap *src, Ho
         return 0; /* failed, or bigger than the original */
     }
     out->is_lossy = 1;
-    if (!has_alpha) {
-        out->type = HOST_IMAGE_TYPE_JPEG;
-        out->comp_buf = j->data.bufs_head;
-        out->comp_buf_size = (uint32_t)jpeg_size;
-        return 1;
-    }
-    /* the alpha plane is lz_encode(LZ_IMAGE_TYPE_XXXA) appended to the same
-     * chain (server/red_worker.c:6281-6300); lz_encode is spice-common's */
-    out->type = HOST_IMAGE_TYPE_JPEG_ALPHA;
+    out->type = HOST_IMAGE_TYPE_JPEG;
     out->comp_buf = j->data.bufs_head;
-    out->jpeg_size = (uint32_t)jpeg_size;
     out->comp_buf_size = (uint32_t)jpeg_size;
     return 1;
 }
@@ -499,10 +498,10 @@ int host_compress_image(HostDisplayClient *dcc, const HostBitmap *src, int can_l
     switch (codec) {
     case SPICE_GPU_CODEC_QUIC:
         out->type = HOST_IMAGE_TYPE_QUIC; /* red_quic_compress_image: spice-common */
-        return 1;
+        return HOST_COMPRESS_DELEGATE;
     case SPICE_GPU_CODEC_LZ:
         out->type = HOST_IMAGE_TYPE_LZ_RGB; /* red_lz_compress_image: spice-common */
-        return 1;
+        return HOST_COMPRESS_DELEGATE;
     case SPICE_GPU_CODEC_JPEG:
         return jpeg_compress_image(dcc, src, out);
     case SPICE_GPU_CODEC_GLZ:

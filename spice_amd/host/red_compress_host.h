@@ -63,10 +63,10 @@ enum {
 /* SpiceImage descriptor + compress_send_data_t (server/red_worker.c:5996-6001) */
 typedef struct HostCompressed {
     int type;                 /* HOST_IMAGE_TYPE_* */
-    RedCompressBuf *comp_buf; /* NULL when the codec belongs to spice-common (QUIC, LZ) */
+    RedCompressBuf *comp_buf; /* the image's bytes; NULL with HOST_COMPRESS_DELEGATE */
     uint32_t comp_buf_size;
     uint32_t glz_data_size;   /* ZLIB_GLZ_RGB: size of the GLZ stream inside */
-    uint32_t jpeg_size;       /* JPEG_ALPHA: size of the JPEG part (the LZ alpha part is not produced) */
+    uint32_t jpeg_size;       /* JPEG_ALPHA: size of the JPEG part (never set: JPEG_ALPHA is delegated) */
     int is_lossy;
     GlzEncDictImageContext *glz_image;
 } HostCompressed;
@@ -81,8 +81,16 @@ const char *host_last_error(const HostDisplayClient *dcc);
 /* GlzUsrImageContext values handed to free_image since the last call */
 int host_pop_freed_images(HostDisplayClient *dcc, uintptr_t *out, int max);
 
-/* red_compress_image.  0 = the bitmap goes out uncompressed (the reference's
- * FALSE).  drawable_graduality: BITMAP_GRADUAL_INVALID to have it computed. */
+/* red_compress_image.  Returns
+ *   1  out holds a complete image of out->type (the reference's TRUE);
+ *   0  the bitmap goes out uncompressed (the reference's FALSE);
+ *   HOST_COMPRESS_DELEGATE  the reference would code the bitmap with an encoder
+ *      of spice-common (QUIC, LZ, or JPEG plus the LZ-coded alpha plane), which
+ *      this library does not replace: out->type names it, out carries no data,
+ *      and the caller runs that encoder itself or sends the bitmap raw.  It is
+ *      never success: a caller that only tests for non-zero must treat it as 0.
+ * drawable_graduality: BITMAP_GRADUAL_INVALID to have it computed. */
+#define HOST_COMPRESS_DELEGATE 2
 int host_compress_image(HostDisplayClient *dcc, const HostBitmap *src, int can_lossy,
                         int drawable_graduality, uintptr_t glz_usr_context, HostCompressed *out);
 /* marshaller_add_compressed: the chain's bytes in order */

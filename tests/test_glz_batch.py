@@ -84,14 +84,138 @@ def test_sim_batch_of_mixed_sessions(sim, oracle):
     run_batches(sim, oracle, SMALL, 4, window=1 << 15)
 
 
-def test_sim_two_jobs_on_one_dictionary_are_refused(sim, oracle):
-    s = Session(sim, oracle, B.LZ_IMAGE_TYPE_RGB32, 32, 8, "flat", seed=1, window=1 << 12)
+class Client:
+    """One client with `nchan` display channels: `nchan` encoders on ONE dictionary
+    (server/red_worker.c:9677-9754), every channel with its own picture sequence.
+    The oracle is fed the same images in the same order through the same encoder ids."""
+
+    def __init__(self, dev, oracle, nchan, w, h, window, seed, typ=B.LZ_IMAGE_TYPE_RGB32):
+        self.dev, self.w, self.h, self.typ, self.nchan = dev, w, h, typ, nchan
+        self.rng = np.random.default_rng(seed)
+        self.seqs = [frames.DesktopSequence(max(w, 96), max(h, 96), seed * 10 + c) for c in range(nchan)]
+        self.od = oracle.GlzDict(window, nchan)
+        self.gd = B.GlzDictionary(dev, window, nchan)
+        self.ges = [B.GlzEncoder(dev, self.gd, c) for c in range(nchan)]
+        self.cap = dev.L.spice_gpu_glz_out_bound(typ, w, h)
+        self.outs = [dev.malloc(self.cap) for _ in range(nchan + 1)]   # one per job of a batch
+        self.held, self.px, self.tag = [], [], 0
+
+    def items(self, order=None):
+        """one job per channel, in `order` (default 0..nchan-1)"""
+        self.order = list(order if order is not None else range(self.nchan))
+        self.px, self.held, its = [], [], []
+        for k, c in enumerate(self.order):
+            px = pixels_for(self.typ, self.seqs[c].next()[:self.h, :self.w].copy(), self.rng)
+            p = self.dev.to_device(px)
+            self.px.append(px)
+            self.held.append(p)
+            its.append(dict(encoder=self.ges[c], type=self.typ, width=self.w, height=self.h,
+                            stride=px.shape[1], chunks=[p], chunk_rows=[self.h], out=self.outs[k],
+                            out_capacity=self.cap, usr_context=5000 + self.tag))
+            self.tag += 1
+        return its
+
+    def check(self, sizes, what):
+        tag0 = self.tag - len(self.order)
+        for k, (c, n) in enumerate(zip(self.order, sizes)):
+            want, _ = self.od.encode(self.typ, self.w, self.h, self.px[k].shape[1], [self.px[k]],
+                                     encoder_id=c, usr_tag=5000 + tag0 + k)
+            assert n > 0, what
+            assert_same_stream(want, self.dev.download(self.outs[k], n), "%s channel %d" % (what, c))
+        assert self.od.pop_freed() == self.gd.usr.freed_images, what
+        self.gd.usr.freed_images.clear()
+        for p in self.held:
+            self.dev.free(p)
+
+    def close(self):
+        for o in self.outs:
+            self.dev.free(o)
+        for e in self.ges:
+            e.close()
+        self.gd.close()
+        self.od.close()
+
+
+def run_shared_dictionary(dev, oracle, w, h, window, nframes, nclients=2, nchan=4):
+    """batches that hold several images per dictionary: the channels of a client, in
+    the caller's order, between sessions that have a dictionary to themselves"""
+    clients = [Client(dev, oracle, nchan, w, h, window, seed=3 + k) for k in range(nclients)]
+    solo = [Session(dev, oracle, B.LZ_IMAGE_TYPE_RGB32, w // 2 + 3, h // 2 + 1, kind, seed=90 + k,
+                    window=window) for k, kind in enumerate(("desktop", "noise"))]
     try:
-        it = s.next_image()
-        with pytest.raises(B.SpiceGpuError, match="share a dictionary"):
-            B.glz_encode_batch(sim, [it, dict(it)])
+        for f in range(nframes):
+            order = list(range(nchan))
+            if f % 2:
+                order = order[::-1] + [0]        # another order, and one channel twice
+            groups = [c.items(order) for c in clients]
+            singles = [s.next_image() for s in solo]
+            # interleave: client 0's first, a solo, client 1's first, ... keeps per-dictionary order
+            items, owner = [], []
+            for k in range(max(len(g) for g in groups)):
+                for ci, g in enumerate(groups):
+                    if k < len(g):
+                        items.append(g[k])
+                        owner.append(("c", ci, k))
+                if k < len(singles):
+                    items.append(singles[k])
+                    owner.append(("s", k, 0))
+            sizes, _ = B.glz_encode_batch(dev, items, split=bool(f % 2))
+            for ci, c in enumerate(clients):
+                mine = [sizes[i] for i, o in enumerate(owner) if o[0] == "c" and o[1] == ci]
+                c.check(mine, "frame %d client %d" % (f, ci))
+            for k, s in enumerate(solo):
+                s.check(sizes[owner.index(("s", k, 0))], "frame %d solo %d" % (f, k))
     finally:
-        s.close()
+        for c in clients:
+            c.close()
+        for s in solo:
+            s.close()
+
+
+def test_sim_shared_dictionary_batch(sim, oracle):
+    # the window holds about six of the images, so every batch evicts
+    run_shared_dictionary(sim, oracle, 96, 40, window=96 * 40 * 6 + 100, nframes=4)
+
+
+def test_sim_failed_batches_leave_windows_usable(sim, oracle):
+    """a batch that is refused changes nothing; a job whose output does not fit leaves a
+    dead image behind (as after remove_image) and the sessions carry on"""
+    specs = [(B.LZ_IMAGE_TYPE_RGB32, 96, 40, "desktop"), (B.LZ_IMAGE_TYPE_RGB32, 64, 32, "noise"),
+             (B.LZ_IMAGE_TYPE_RGB32, 80, 30, "desktop")]
+    sessions = [Session(sim, oracle, *spec, seed=11 + k, window=1 << 14) for k, spec in enumerate(specs)]
+    try:
+        items = [s.next_image() for s in sessions]
+        sizes, _ = B.glz_encode_batch(sim, items)
+        for s, n in zip(sessions, sizes):
+            s.check(n, "first batch")
+        # (1) the last job is invalid: refused before any window is touched
+        items = [s.next_image() for s in sessions]
+        bad = dict(items[2], stride=items[2]["stride"] + 4)
+        with pytest.raises(B.SpiceGpuError, match="stride"):
+            B.glz_encode_batch(sim, items[:2] + [bad])
+        sizes, _ = B.glz_encode_batch(sim, items)          # the same images, now accepted
+        for s, n in zip(sessions, sizes):
+            s.check(n, "after a refused batch")
+        # (2) the noise session's output buffer is too small: that job fails on the device
+        items = [s.next_image() for s in sessions]
+        items[1] = dict(items[1], out_capacity=200)
+        sizes, imgs = B.glz_encode_batch(sim, items, raise_on_error=False)
+        assert sizes[1] < 0 and imgs[1] is None and sizes[0] > 0 and sizes[2] > 0
+        sessions[0].check(sizes[0], "beside a failed job")
+        sessions[2].check(sizes[2], "beside a failed job")
+        s1 = sessions[1]
+        _, dead = s1.od.encode(s1.typ, s1.w, s1.h, s1.stride, s1.chunks)   # the oracle: encode, then remove
+        s1.od.remove_image(dead)
+        for p in s1.held:
+            sim.free(p)
+        for f in range(3):
+            items = [s.next_image() for s in sessions]
+            sizes, _ = B.glz_encode_batch(sim, items)
+            for s, n in zip(sessions, sizes):
+                s.check(n, "batch %d after a failed job" % f)
+    finally:
+        for s in sessions:
+            s.close()
 
 
 def run_plan(dev, oracle, n, w, h, nframes, window):
@@ -138,6 +262,11 @@ def test_gpu_batch_of_mixed_sessions(gpu, oracle):
     big = SMALL + [(B.LZ_IMAGE_TYPE_RGB32, 640, 400, "desktop"), (B.LZ_IMAGE_TYPE_RGB32, 320, 200, "noise"),
                    (B.LZ_IMAGE_TYPE_RGBA, 300, 300, "desktop"), (B.LZ_IMAGE_TYPE_RGB32, 1024, 64, "flat")]
     run_batches(gpu, oracle, big, 6, window=1 << 19)
+
+
+@pytest.mark.gpu
+def test_gpu_shared_dictionary_batch(gpu, oracle):
+    run_shared_dictionary(gpu, oracle, 320, 200, window=320 * 200 * 6 + 100, nframes=5)
 
 
 @pytest.mark.gpu
