@@ -351,6 +351,21 @@ int spice_gpu_jpeg_encode_batch(SpiceGpuJpegJob *jobs, int njobs);
 int spice_gpu_jpeg_submit(SpiceGpuJpegJob *jobs, int njobs);
 int spice_gpu_jpeg_finish(SpiceGpuJpegJob *jobs, int njobs);
 
+/* One frame, like a spice_gpu_jpeg_encode_batch of one job, but without any
+ * allocation: no counterpart in the reference; it is for callers that cannot
+ * allocate device memory where they call from (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid it).  The kernels' scratch (the
+ * strips' Huffman bits, their counts and offsets, the unstuffed scan, the job
+ * record) lives in an 18 MB array inside the library's code object, one copy per
+ * GPU, held until the process ends.  Limits: at most 1024 strips of 10 MCUs
+ * (rows of 16 pixels x ceil(ceil(width / 16) / 10); 1920x1088 has 816) and
+ * out_capacity <= 4 MiB; beyond them the call fails with a message and the
+ * batch interface must be used.  spice_gpu_init must have run.  Calls on one GPU
+ * share that GPU's array: the library serialises them, and nothing else may use
+ * the result of one call's scratch.  Same output bytes as the batch interface.
+ * Returns 0 with job->out_size set, or -1. */
+int spice_gpu_jpeg_encode_noalloc(SpiceGpuJpegJob *job);
+
 /* ---- Section 3: what decides between the codecs ------------------------
  *
  * Graduality of a bitmap, _get_bitmap_graduality_level

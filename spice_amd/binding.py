@@ -166,7 +166,7 @@ EXPORTS = [
     "jpeg_encoder_create", "jpeg_encoder_destroy", "jpeg_encode",
     "spice_gpu_glz_out_bound", "spice_gpu_glz_encode_batch", "spice_gpu_glz_submit",
     "spice_gpu_glz_finish", "spice_gpu_glz_last_batch_host_ns", "spice_gpu_jpeg_out_bound", "spice_gpu_jpeg_encode_batch",
-    "spice_gpu_jpeg_submit", "spice_gpu_jpeg_finish", "spice_gpu_malloc", "spice_gpu_free",
+    "spice_gpu_jpeg_submit", "spice_gpu_jpeg_finish", "spice_gpu_jpeg_encode_noalloc", "spice_gpu_malloc", "spice_gpu_free",
     "spice_gpu_upload", "spice_gpu_download", "spice_gpu_get_stats", "spice_gpu_reset_stats",
     "spice_gpu_timing_enable", "spice_gpu_timing_reset", "spice_gpu_timing_read",
     "spice_gpu_graduality_batch", "spice_gpu_bitmap_graduality_level", "spice_gpu_choose_codec",
@@ -238,6 +238,8 @@ class SpiceGpu:
         for n in ("spice_gpu_jpeg_encode_batch", "spice_gpu_jpeg_submit", "spice_gpu_jpeg_finish"):
             getattr(L, n).restype = i
             getattr(L, n).argtypes = [C.POINTER(SpiceGpuJpegJob), i]
+        L.spice_gpu_jpeg_encode_noalloc.restype = i
+        L.spice_gpu_jpeg_encode_noalloc.argtypes = [C.POINTER(SpiceGpuJpegJob)]
         L.spice_gpu_malloc.restype, L.spice_gpu_malloc.argtypes = vp, [C.c_size_t]
         L.spice_gpu_free.argtypes = [vp]
         L.spice_gpu_upload.restype, L.spice_gpu_upload.argtypes = i, [vp, vp, C.c_size_t]
@@ -741,6 +743,19 @@ def jpeg_encode_batch(gpu, items):
     if gpu.L.spice_gpu_jpeg_encode_batch(jobs, n) != 0:
         raise SpiceGpuError("jpeg batch: " + gpu.last_error())
     return [jobs[j].out_size for j in range(n)]
+
+
+def jpeg_encode_noalloc(gpu, item):
+    """One frame through spice_gpu_jpeg_encode_noalloc (same item keys as
+    jpeg_encode_batch).  Returns the JFIF size."""
+    job = SpiceGpuJpegJob()
+    job.pixels, job.format = item["pixels"], item["format"]
+    job.width, job.height, job.stride = item["width"], item["height"], item["stride"]
+    job.quality, job.dct = item["quality"], item["dct"]
+    job.out, job.out_capacity = item["out"], item["out_capacity"]
+    if gpu.L.spice_gpu_jpeg_encode_noalloc(C.byref(job)) != 0:
+        raise SpiceGpuError("jpeg (no allocation): " + gpu.last_error())
+    return job.out_size
 
 
 class JpegBatchPlan:

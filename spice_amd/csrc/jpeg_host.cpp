@@ -20,7 +20,8 @@
 using namespace spicegpu;
 
 void jpeg_launch(const JpegDevJob *jobs, int njobs, int max_groups, bool any_islow, bool any_ifast,
-                 const uint32_t *huff, hipStream_t stream);
+                 const uint32_t *huff, hipStream_t stream, bool timed = true);
+void jpeg_huff_words(uint32_t *h);
 
 namespace {
 
@@ -219,6 +220,27 @@ bool fill_job(JpegDevJob *j, const void *pixels, int format, int width, int heig
     return true;
 }
 
+} // namespace
+
+/* for the entry point that allocates nothing (jpeg_kernels.hip) */
+bool jpeg_fill_job(JpegDevJob *j, const void *pixels, int format, int width, int height, long stride,
+                   int quality, int dct, void *out, uint32_t out_cap)
+{
+    return fill_job(j, pixels, format, width, height, stride, quality, dct, out, out_cap);
+}
+
+/* the four standard Huffman tables as the kernels read them: AC luma, AC chroma,
+ * DC luma, DC chroma */
+void jpeg_huff_words(uint32_t *h)
+{
+    pack_huff(kAcLumaBits, kAcLumaVals, h, 256);
+    pack_huff(kAcChromaBits, kAcChromaVals, h + 256, 256);
+    pack_huff(kDcLumaBits, kDcVals, h + 512, 16);
+    pack_huff(kDcChromaBits, kDcVals, h + 528, 16);
+}
+
+namespace {
+
 /* Library-owned device scratch for one batch (guarded by the device gate). */
 struct JpegFlight {
     Staging staging;      /* JpegDevJob array + results */
@@ -239,10 +261,7 @@ bool ensure_huff(JpegFlight &f)
         return true;
     }
     uint32_t h[JPEG_HUFF_WORDS];
-    pack_huff(kAcLumaBits, kAcLumaVals, h, 256);
-    pack_huff(kAcChromaBits, kAcChromaVals, h + 256, 256);
-    pack_huff(kDcLumaBits, kDcVals, h + 512, 16);
-    pack_huff(kDcChromaBits, kDcVals, h + 528, 16);
+    jpeg_huff_words(h);
     if (!check(hipMalloc((void **)&f.d_huff, sizeof(h)), "hipMalloc huff")) {
         return false;
     }

@@ -1194,26 +1194,182 @@ jpeg_finish_kernel(const JpegDevJob *jobs)
     }
 }
 
+/* timed = false: no timing events round the launches (creating an event allocates) */
 void jpeg_launch(const JpegDevJob *jobs, int njobs, int max_groups, bool any_islow, bool any_ifast,
-                 const uint32_t *huff, hipStream_t stream)
+                 const uint32_t *huff, hipStream_t stream, bool timed)
 {
     const dim3 grid((unsigned)max_groups, (unsigned)njobs);
-    int t;
+    int t = -1;
     if (any_islow) {
-        t = spicegpu::timing_begin("jpeg_strip_kernel_islow", stream);
+        t = timed ? spicegpu::timing_begin("jpeg_strip_kernel_islow", stream) : -1;
         hipLaunchKernelGGL(jpeg_strip_kernel<false>, grid, dim3(JT), 0, stream, jobs, huff);
         spicegpu::timing_end(t, stream);
     }
     if (any_ifast) {
-        t = spicegpu::timing_begin("jpeg_strip_kernel_ifast", stream);
+        t = timed ? spicegpu::timing_begin("jpeg_strip_kernel_ifast", stream) : -1;
         hipLaunchKernelGGL(jpeg_strip_kernel<true>, grid, dim3(JT), 0, stream, jobs, huff);
         spicegpu::timing_end(t, stream);
     }
     /* the three bit-stream kernels share one pair of timing events: an event
      * between two launches costs about as much as the offsets kernel itself */
-    t = spicegpu::timing_begin("jpeg_bitstream_kernels", stream);
+    t = timed ? spicegpu::timing_begin("jpeg_bitstream_kernels", stream) : -1;
     hipLaunchKernelGGL(jpeg_offsets_kernel, dim3((unsigned)njobs), dim3(JT), 0, stream, jobs);
     hipLaunchKernelGGL(jpeg_gather_kernel, dim3(64, (unsigned)njobs), dim3(JT), 0, stream, jobs);
     hipLaunchKernelGGL(jpeg_finish_kernel, dim3(64, (unsigned)njobs), dim3(JT), 0, stream, jobs);
     spicegpu::timing_end(t, stream);
+}
+
+/* ---------------------------------------------------------------------------
+ * One frame through the same kernels with no allocation of any kind: for callers
+ * that cannot allocate device memory where they call from (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid it).  What
+ * spice_gpu_jpeg_encode_batch takes from hipMalloc'ed, growing buffers -- the job
+ * record, the Huffman tables, the strips' bit slots, their counts and offsets,
+ * the unstuffed scan and the 0xFF counts -- lives in one array of the code
+ * object instead.  Every GPU the library runs on holds its own copy of the array
+ * until the process ends.
+ *
+ * Layout of the array (byte offsets):
+ *   0        the JpegDevJob of the call in progress
+ *   2048     its result (int32)
+ *   4096     Huffman tables, JPEG_HUFF_WORDS words (written once, at set-up)
+ *   8192     strip_bits      JPEG_NA_MAX_STRIPS words
+ *   12288    strip_bitoff    JPEG_NA_MAX_STRIPS + 1 quad words
+ *   24576    chunk_ff        words, one per 4 KiB of the unstuffed scan
+ *   36864    scan_buf        JPEG_NA_MAX_OUT + 512 bytes
+ *   ...      strip_buf       JPEG_NA_MAX_STRIPS slots of JPEG_NA_STRIP_STRIDE bytes
+ * No kernel of the pipeline expects any of it to be zero: every strip writes its
+ * count, offsets and chunk counts are written for every entry that is read, and
+ * the gather kernel cuts what it reads of a slot to the bits the strip produced.
+ */
+#define JPEG_NA_MAX_STRIPS 1024          /* e.g. 1920 x 1088: 12 strips x 68 MCU rows = 816 */
+#define JPEG_NA_MAX_OUT (4u << 20)       /* largest out_capacity */
+#define JPEG_NA_STRIP_STRIDE (JPEG_MCU_SLOT_BYTES * JPEG_STRIP_MCUS)
+#define JPEG_NA_OFF_RESULT 2048u
+#define JPEG_NA_OFF_HUFF 4096u
+#define JPEG_NA_OFF_BITS 8192u
+#define JPEG_NA_OFF_BITOFF 12288u
+#define JPEG_NA_OFF_CHUNKFF 24576u
+#define JPEG_NA_OFF_SCAN 36864u
+#define JPEG_NA_SCAN_BYTES (JPEG_NA_MAX_OUT + 512u)
+#define JPEG_NA_OFF_STRIPS (JPEG_NA_OFF_SCAN + JPEG_NA_SCAN_BYTES)
+#define JPEG_NA_BYTES (JPEG_NA_OFF_STRIPS + JPEG_NA_MAX_STRIPS * JPEG_NA_STRIP_STRIDE + 256u)
+#define JPEG_NA_MAX_DEVICES 64
+
+static_assert(sizeof(JpegDevJob) <= JPEG_NA_OFF_RESULT, "job record overlaps the result");
+static_assert(JPEG_HUFF_WORDS * 4 <= JPEG_NA_OFF_BITS - JPEG_NA_OFF_HUFF, "Huffman tables overlap");
+static_assert((JPEG_NA_MAX_STRIPS + 1) * 8 <= JPEG_NA_OFF_CHUNKFF - JPEG_NA_OFF_BITOFF, "offsets overlap");
+static_assert((JPEG_NA_SCAN_BYTES / JPEG_CHUNK_BYTES + 2) * 4 <= JPEG_NA_OFF_SCAN - JPEG_NA_OFF_CHUNKFF,
+              "chunk counts overlap");
+
+/* In host code this name is a stand-in, not a device address: the address comes
+ * from hipGetSymbolAddress, once per device (jpeg_noalloc_setup). */
+static __device__ __align__(256) uint8_t jpeg_na_scratch[JPEG_NA_BYTES];
+
+/* device address of jpeg_na_scratch on each GPU this process has initialised */
+static uint8_t *g_jpeg_na_ptr[JPEG_NA_MAX_DEVICES];
+
+bool jpeg_fill_job(JpegDevJob *j, const void *pixels, int format, int width, int height, long stride,
+                   int quality, int dct, void *out, uint32_t out_cap);
+void jpeg_huff_words(uint32_t *h);
+
+/* the job record travels as a kernel argument: no host-to-device copy is needed */
+__global__ void __launch_bounds__(64)
+jpeg_na_put_job(const JpegDevJob job, JpegDevJob *dst)
+{
+    if (threadIdx.x == 0) {
+        *dst = job;
+    }
+}
+
+/* Called by spice_gpu_init with `device` current. */
+bool jpeg_noalloc_setup(int device)
+{
+    if (device < 0 || device >= JPEG_NA_MAX_DEVICES) {
+        spicegpu::set_error("device %d: the library handles devices 0..%d", device, JPEG_NA_MAX_DEVICES - 1);
+        return false;
+    }
+    if (g_jpeg_na_ptr[device]) {
+        return true;
+    }
+    uint8_t *ptr = nullptr;
+    if (!spicegpu::check(hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(jpeg_na_scratch)),
+                         "hipGetSymbolAddress(jpeg_na_scratch)") || !ptr) {
+        return false;
+    }
+    uint32_t h[JPEG_HUFF_WORDS];
+    jpeg_huff_words(h);
+    if (!spicegpu::check(hipMemcpy(ptr + JPEG_NA_OFF_HUFF, h, sizeof(h), hipMemcpyHostToDevice),
+                         "upload Huffman tables")) {
+        return false;
+    }
+    g_jpeg_na_ptr[device] = ptr;
+    return true;
+}
+
+extern "C" int spice_gpu_jpeg_encode_noalloc(SpiceGpuJpegJob *job)
+{
+    using namespace spicegpu;
+    const int device = current_device();
+    if (device < 0 || !g_jpeg_na_ptr[device]) {
+        set_error("jpeg (no allocation): call spice_gpu_init first");
+        return -1;
+    }
+    if (!job) {
+        set_error("jpeg (no allocation): null job");
+        return -1;
+    }
+    job->out_size = -1;
+    uint8_t *const ptr = g_jpeg_na_ptr[device];
+    static JpegDevJob dj; /* guarded by the device gate */
+    GateHold gate("jpeg (no allocation)");
+    if (!gate.ok) {
+        return -1;
+    }
+    if (!check(hipSetDevice(device), "hipSetDevice")) {
+        return -1;
+    }
+    if (!job->pixels || !job->out ||
+        !jpeg_fill_job(&dj, job->pixels, job->format, job->width, job->height, job->stride,
+                       job->quality, job->dct, job->out, job->out_capacity)) {
+        set_error("jpeg (no allocation): unsupported parameters");
+        return -1;
+    }
+    if (dj.nstrips > JPEG_NA_MAX_STRIPS || job->out_capacity > JPEG_NA_MAX_OUT) {
+        set_error("jpeg (no allocation): %d strips of 10 MCUs / %u output bytes exceed the maximum of "
+                  "%d strips / %u bytes (use spice_gpu_jpeg_encode_batch)",
+                  dj.nstrips, job->out_capacity, JPEG_NA_MAX_STRIPS, JPEG_NA_MAX_OUT);
+        return -1;
+    }
+    dj.strip_stride = JPEG_NA_STRIP_STRIDE;
+    dj.scan_cap = (job->out_capacity + 64 + 255) & ~255u;
+    dj.nchunks_cap = dj.scan_cap / JPEG_CHUNK_BYTES + 1;
+    dj.strip_buf = ptr + JPEG_NA_OFF_STRIPS;
+    dj.strip_bits = (uint32_t *)(ptr + JPEG_NA_OFF_BITS);
+    dj.strip_bitoff = (uint64_t *)(ptr + JPEG_NA_OFF_BITOFF);
+    dj.scan_buf = ptr + JPEG_NA_OFF_SCAN;
+    dj.chunk_ff = (uint32_t *)(ptr + JPEG_NA_OFF_CHUNKFF);
+    dj.result = (int32_t *)(ptr + JPEG_NA_OFF_RESULT);
+
+    const uint64_t t0 = now_ns();
+    hipStream_t s = stream();
+    const int groups = (dj.strips_per_row + JPEG_GROUP_STRIPS - 1) / JPEG_GROUP_STRIPS * dj.mcu_rows;
+    hipLaunchKernelGGL(jpeg_na_put_job, dim3(1), dim3(64), 0, s, dj, (JpegDevJob *)ptr);
+    jpeg_launch((const JpegDevJob *)ptr, 1, groups, dj.dct == 0, dj.dct != 0,
+                (const uint32_t *)(ptr + JPEG_NA_OFF_HUFF), s, false);
+    int32_t size = 0;
+    if (!check(hipGetLastError(), "jpeg launch") ||
+        !check(hipMemcpyAsync(&size, ptr + JPEG_NA_OFF_RESULT, sizeof(size), hipMemcpyDeviceToHost, s),
+               "read result") ||
+        !check(hipStreamSynchronize(s), "jpeg sync")) {
+        return -1;
+    }
+    job->out_size = size;
+    if (size <= 0) {
+        set_error("jpeg (no allocation): output does not fit (%d)", size);
+        return -1;
+    }
+    stat_add(SPICE_GPU_STAT_MJPEG, (uint64_t)dj.width * (uint64_t)dj.height * 4u, (uint64_t)size,
+             now_ns() - t0);
+    return 0;
 }

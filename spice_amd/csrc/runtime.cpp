@@ -13,6 +13,8 @@
 #include <thread>
 #include <vector>
 
+bool jpeg_noalloc_setup(int device); /* jpeg_kernels.hip */
+
 namespace spicegpu {
 
 namespace {
@@ -72,6 +74,10 @@ static bool init_locked(int device)
                             check(hipEventCreate(&g_join), "hipEventCreate"))) {
         return false;
     }
+    /* the device-resident scratch of the entry point that allocates nothing */
+    if (!jpeg_noalloc_setup(device)) {
+        return false;
+    }
     g_device = device;
     g_ready = true;
     return true;
@@ -85,6 +91,11 @@ bool ensure_init()
         return check(hipSetDevice(g_device), "hipSetDevice");
     }
     return init_locked(0);
+}
+
+int current_device()
+{
+    return g_ready ? g_device : -1;
 }
 
 hipStream_t stream()

@@ -19,6 +19,8 @@ namespace spicegpu {
 /* Makes sure spice_gpu_init ran (initialises device 0 on first use).
  * Returns false, with the error text set, when no GPU can be used. */
 bool ensure_init();
+/* the device spice_gpu_init selected, or -1 before it ran */
+int current_device();
 hipStream_t stream();
 /* a second stream for work that may run beside stream()'s, and two events to order them */
 hipStream_t side_stream();

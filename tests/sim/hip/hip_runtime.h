@@ -34,7 +34,6 @@
 #define __shared__ static
 #define __constant__ static
 #define __align__(n) __attribute__((aligned(n)))
-#define HIP_SYMBOL(x) (&(x))
 
 typedef int hipError_t;
 enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorUnknown = 999 };
@@ -104,6 +103,13 @@ hipError_t hipGetDeviceCount(int *n);
 hipError_t hipSetDevice(int d);
 hipError_t hipGetDevice(int *d);
 hipError_t hipGetLastError(void);
+/* a __device__ array of the simulator is an ordinary host array */
+#define HIP_SYMBOL(x) x
+template <typename T> inline hipError_t hipGetSymbolAddress(void **p, const T &symbol)
+{
+    *p = (void *)&symbol;
+    return hipSuccess;
+}
 hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int d);
 const char *hipGetErrorString(hipError_t e);
 hipError_t hipEventCreate(hipEvent_t *e);
