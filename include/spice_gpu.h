@@ -124,6 +124,17 @@ typedef struct SpiceGpuGlzDictInfo {
 } SpiceGpuGlzDictInfo;
 void spice_gpu_glz_dictionary_info(GlzEncDictContext *opaque_dict, SpiceGpuGlzDictInfo *out);
 
+/* The window's bookkeeping as it stands (SharedDictionary's lists,
+ * server/glz_encoder_dictionary_protected.h:80-126), for checkers: writes at
+ * most cap words and returns how many the dump has.  Words: size limit, max
+ * encoders, last image id, pixels so far, segment slots, used segments head and
+ * tail, every encoder's head (0xffffffff = none); the number of images in the
+ * window, then per image oldest first: id, size in pixels, alive, usr_context,
+ * LzImageType, number of segments, and per segment: slot, pixels_so_far,
+ * pixels_num, next slot; at last the free segment slots, a count and then the
+ * slots in the order in which they will be handed out. */
+size_t spice_gpu_glz_dictionary_dump(GlzEncDictContext *opaque_dict, uint64_t *out, size_t cap);
+
 /* server/glz_encoder.h:30-33 */
 GlzEncoderContext *glz_encoder_create(uint8_t id, GlzEncDictContext *dictionary,
                                       GlzEncoderUsrContext *usr);

@@ -156,7 +156,7 @@ EXPORTS = [
     "spice_gpu_init", "spice_gpu_shutdown", "spice_gpu_last_error", "spice_gpu_stream",
     "glz_enc_dictionary_create", "glz_enc_dictionary_destroy", "glz_enc_dictionary_get_size",
     "glz_enc_dictionary_get_restore_data", "glz_enc_dictionary_restore", "glz_enc_dictionary_reset",
-    "glz_enc_dictionary_remove_image", "spice_gpu_glz_dictionary_info", "glz_encoder_create", "glz_encoder_destroy", "glz_encode",
+    "glz_enc_dictionary_remove_image", "spice_gpu_glz_dictionary_info", "spice_gpu_glz_dictionary_dump", "glz_encoder_create", "glz_encoder_destroy", "glz_encode",
     "mjpeg_encoder_new", "mjpeg_encoder_destroy", "mjpeg_encoder_get_bytes_per_pixel",
     "mjpeg_encoder_start_frame", "mjpeg_encoder_encode_scanline", "mjpeg_encoder_end_frame",
     "mjpeg_encoder_get_bit_rate", "mjpeg_encoder_get_stats",
@@ -199,6 +199,8 @@ class SpiceGpu:
         L.glz_enc_dictionary_reset.argtypes = [vp, vp]
         L.glz_enc_dictionary_remove_image.argtypes = [vp, vp, vp]
         L.spice_gpu_glz_dictionary_info.argtypes = [vp, C.POINTER(SpiceGpuGlzDictInfo)]
+        L.spice_gpu_glz_dictionary_dump.restype = C.c_size_t
+        L.spice_gpu_glz_dictionary_dump.argtypes = [vp, C.POINTER(C.c_uint64), C.c_size_t]
         L.glz_encoder_create.restype, L.glz_encoder_create.argtypes = vp, [C.c_uint8, vp, vp]
         L.glz_encoder_destroy.argtypes = [vp]
         L.glz_encode.restype = i
@@ -405,6 +407,24 @@ class GlzDictionary:
 
     def remove_image(self, image):
         self.gpu.L.glz_enc_dictionary_remove_image(self.h, image, self.usr.ptr)
+
+    def dump(self):
+        """the window's bookkeeping (spice_gpu_glz_dictionary_dump) as a dict"""
+        n = self.gpu.L.spice_gpu_glz_dictionary_dump(self.h, None, 0)
+        buf = (C.c_uint64 * n)()
+        assert self.gpu.L.spice_gpu_glz_dictionary_dump(self.h, buf, n) == n
+        w = iter(buf)
+        d = dict(size_limit=next(w), max_encoders=next(w), last_image_id=next(w), pixels_so_far=next(w),
+                 seg_slots=next(w), used_segs_head=next(w), used_segs_tail=next(w))
+        d["encoders_heads"] = [next(w) for _ in range(d["max_encoders"])]
+        d["images"] = []
+        for _ in range(next(w)):
+            im = dict(id=next(w), size=next(w), alive=bool(next(w)), usr_context=next(w), type=next(w))
+            im["segs"] = [dict(slot=next(w), pixels_so_far=next(w), pixels_num=next(w), next=next(w))
+                          for _ in range(next(w))]
+            d["images"].append(im)
+        d["free_segs"] = [next(w) for _ in range(next(w))]
+        return d
 
 
 class GlzEncoder:

@@ -939,6 +939,63 @@ void spice_gpu_glz_dictionary_info(GlzEncDictContext *opaque_dict, SpiceGpuGlzDi
     }
 }
 
+size_t spice_gpu_glz_dictionary_dump(GlzEncDictContext *opaque_dict, uint64_t *out, size_t cap)
+{
+    Dict *d = (Dict *)opaque_dict;
+    std::lock_guard<std::recursive_mutex> lock(d->lock);
+    size_t n = 0;
+    auto put = [&](uint64_t v) {
+        if (n < cap) {
+            out[n] = v;
+        }
+        n++;
+    };
+    put(d->size_limit);
+    put(d->max_encoders);
+    put(d->last_image_id);
+    put(d->pixels_so_far);
+    put(d->segs.size());
+    put(d->used_segs_head);
+    put(d->used_segs_tail);
+    for (uint32_t h : d->encoders_heads) {
+        put(h);
+    }
+    uint64_t nimages = 0;
+    for (HostImage *im = d->used_images_head; im; im = im->next) {
+        nimages++;
+    }
+    put(nimages);
+    for (HostImage *im = d->used_images_head; im; im = im->next) {
+        put(im->id);
+        put((uint64_t)im->size);
+        put(im->alive ? 1 : 0);
+        put((uint64_t)(uintptr_t)im->usr_context);
+        put((uint64_t)im->type);
+        uint64_t nsegs = 0;
+        for (uint32_t sid = im->first_seg; sid != kNullSeg && d->segs[sid].image == im;
+             sid = d->segs[sid].next) {
+            nsegs++;
+        }
+        put(nsegs);
+        for (uint32_t sid = im->first_seg; sid != kNullSeg && d->segs[sid].image == im;
+             sid = d->segs[sid].next) {
+            put(sid);
+            put(d->segs[sid].pixels_so_far);
+            put(d->segs[sid].pixels_num);
+            put(d->segs[sid].next);
+        }
+    }
+    uint64_t nfree = 0;
+    for (uint32_t sid = d->free_segs_head; sid != kNullSeg; sid = d->segs[sid].next) {
+        nfree++;
+    }
+    put(nfree);
+    for (uint32_t sid = d->free_segs_head; sid != kNullSeg; sid = d->segs[sid].next) {
+        put(sid);
+    }
+    return n;
+}
+
 GlzEncoderContext *glz_encoder_create(uint8_t id, GlzEncDictContext *dictionary,
                                       GlzEncoderUsrContext *usr)
 {

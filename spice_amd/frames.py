@@ -9,6 +9,13 @@ desktop    desktop-like 32-bit frames: flat background, overlapping windows
            finds cross-image matches
 video      a smooth sinusoid field with a moving textured block and +-2 LSB
            noise, the kind of content the stream detector hands to MJPEG
+sessions64 64 independent display sessions, every one a desktop sequence with
+           its own seed; the even ones are the GLZ half, the odd ones the half
+           whose bitmaps score a HIGH graduality and go to QUIC in the reference
+multimon   one client with four 3840x2160 monitors: per tick every monitor
+           sends a desktop-like update of the upper 70 % of its area (GLZ, all
+           four through the client's one shared dictionary) and a video frame
+           of the lower 30 % (MJPEG)
 """
 import numpy as np
 
@@ -186,3 +193,53 @@ def golden_image(width, height, kind, seed):
         raise ValueError(kind)
     a[..., 3] = 0
     return a
+
+
+class Sessions64:
+    """BASELINE configs[3]: 64 concurrent display sessions, each a desktop sequence of
+    its own.  In the reference the sessions whose updates are smooth (graduality HIGH)
+    are coded with QUIC and the others with GLZ (server/red_worker.c:6462-6505); here
+    the odd-numbered sessions stand for the QUIC half and the even ones for the GLZ half."""
+
+    N = 64
+
+    def __init__(self, width=1920, height=1080, seed=640):
+        self.w, self.h, self.seed = width, height, seed
+
+    def session_ids(self, codec):
+        return [c for c in range(self.N) if (c % 2 == 0) == (codec == "glz")]
+
+    def sequence(self, session_id):
+        """the session's frames: DesktopSequence for the GLZ half; the QUIC half gets
+        smooth gradients (what scores HIGH)"""
+        if session_id % 2 == 0:
+            return DesktopSequence(self.w, self.h, seed=self.seed + session_id)
+        return _SmoothSequence(self.w, self.h, seed=self.seed + session_id)
+
+
+class _SmoothSequence:
+    def __init__(self, width, height, seed):
+        self.w, self.h, self.seed, self.k = width, height, seed, 0
+
+    def next(self):
+        self.k += 1
+        return golden_image(self.w, self.h, "smooth", self.seed + self.k)
+
+
+class MultimonClient:
+    """BASELINE configs[4]: one client, `monitors` displays of width x height.  Every
+    tick each monitor yields (desktop region for GLZ, video region for MJPEG): the
+    upper 70 % of the rows and the lower 30 %.  The regions are independent
+    sequences, so a monitor's GLZ updates scroll and blink like a desktop and its
+    video region moves like a video."""
+
+    def __init__(self, width=3840, height=2160, monitors=4, seed=4000):
+        self.w, self.h, self.monitors = width, height, monitors
+        self.glz_rows = height * 7 // 10
+        self.video_rows = height - self.glz_rows
+        self.desk = [DesktopSequence(width, self.glz_rows, seed=seed + 10 * m) for m in range(monitors)]
+        self.video = [VideoSequence(width, self.video_rows, seed=seed + 10 * m + 5) for m in range(monitors)]
+
+    def tick(self):
+        """[(glz region (rows, w, 4), video region (rows, w, 4)) per monitor]"""
+        return [(d.next(), v.next()) for d, v in zip(self.desk, self.video)]

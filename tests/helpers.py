@@ -4,6 +4,8 @@ import numpy as np
 from spice_amd import binding as B
 from spice_amd import frames
 
+from window_model import WindowModel
+
 
 def pixels_for(typ, bgrx, rng):
     """Rows (h, stride) of `bgrx` in the pixel layout of LzImageType `typ`."""
@@ -50,7 +52,14 @@ class GlzPair:
         self.od = oracle.GlzDict(size_px, max_encoders)
         self.gd = B.GlzDictionary(gpu, size_px, max_encoders)
         self.ge = B.GlzEncoder(gpu, self.gd, 0)
+        self.model = WindowModel(size_px, max_encoders)      # independent bookkeeping, see window_model.py
         self.n = 0
+
+    def remove(self, oimg, gimg, tag):
+        """glz_enc_dictionary_remove_image on both sides"""
+        self.od.remove_image(oimg)
+        self.gd.remove_image(gimg)
+        self.model.remove(tag)
 
     def encode(self, typ, w, h, stride, chunks, top_down=True, what="", direct=False):
         tag = 1000 + self.n
@@ -76,6 +85,9 @@ class GlzPair:
                                       first_lines_direct=direct)
         assert_same_stream(so, sg, "%s image %d (%dx%d type %d)" % (what, self.n - 1, w, h, typ))
         assert self.od.pop_freed() == self.gd.usr.freed_images
+        self.model.add(typ, h, stride, [c.shape[0] for c in chunks], tag)
+        assert self.model.pop_freed() == self.gd.usr.freed_images, what
+        self.model.check(self.gd.dump(), "%s image %d" % (what, self.n - 1))
         self.gd.usr.freed_images.clear()
         return so, oimg, gimg
 

@@ -11,6 +11,7 @@ from spice_amd import binding as B
 from spice_amd import frames
 
 from helpers import assert_same_stream, pixels_for, small_desktop, split_rows
+from window_model import WindowModel
 
 
 class Session:
@@ -95,6 +96,7 @@ class Client:
         self.seqs = [frames.DesktopSequence(max(w, 96), max(h, 96), seed * 10 + c) for c in range(nchan)]
         self.od = oracle.GlzDict(window, nchan)
         self.gd = B.GlzDictionary(dev, window, nchan)
+        self.model = WindowModel(window, nchan)
         self.ges = [B.GlzEncoder(dev, self.gd, c) for c in range(nchan)]
         self.cap = dev.L.spice_gpu_glz_out_bound(typ, w, h)
         self.outs = [dev.malloc(self.cap) for _ in range(nchan + 1)]   # one per job of a batch
@@ -122,7 +124,9 @@ class Client:
                                      encoder_id=c, usr_tag=5000 + tag0 + k)
             assert n > 0, what
             assert_same_stream(want, self.dev.download(self.outs[k], n), "%s channel %d" % (what, c))
-        assert self.od.pop_freed() == self.gd.usr.freed_images, what
+            self.model.add(self.typ, self.h, self.px[k].shape[1], [self.h], 5000 + tag0 + k)
+        assert self.od.pop_freed() == self.model.pop_freed() == self.gd.usr.freed_images, what
+        self.model.check(self.gd.dump(), what)
         self.gd.usr.freed_images.clear()
         for p in self.held:
             self.dev.free(p)

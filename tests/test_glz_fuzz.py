@@ -67,8 +67,7 @@ def run_session(dev, oracle, seed, nimages, max_w, max_h, windows=(3000, 20000, 
                                         top_down=bool(rng.integers(0, 2)),
                                         what="fuzz seed %d image %d (%dx%d)" % (seed, i, w, h))
             if rng.random() < 0.08:                 # the newest image is certainly still in the window
-                pair.od.remove_image(oimg)
-                pair.gd.remove_image(gimg)
+                pair.remove(oimg, gimg, 1000 + pair.n - 1)
     finally:
         pair.close()
 

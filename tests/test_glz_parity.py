@@ -30,8 +30,7 @@ def run_mixed_sequence(dev, oracle, typ, nimages, window=40000, batch=False):
             _, oimg, gimg = pair.encode(typ, w, h, px.shape[1], chunks, top_down=bool(i % 2),
                                         what="mixed", direct=(i % 4 == 1))
             if i == 5:
-                pair.od.remove_image(oimg)
-                pair.gd.remove_image(gimg)
+                pair.remove(oimg, gimg, 1000 + pair.n - 1)
     finally:
         pair.close()
 
