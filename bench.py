@@ -55,6 +55,8 @@ def parse_args():
     ap.add_argument("--frames", type=int, default=16, help="MJPEG frames per step per GPU")
     ap.add_argument("--clients", type=int, default=8, help="multimon: four-monitor clients per GPU")
     ap.add_argument("--pool", type=int, default=256, help="distinct synthetic desktop sequences per GPU")
+    ap.add_argument("--out-mb", type=float, default=2.0,
+                    help="GLZ output buffer per session in MiB (0 = the worst-case bound, 10 MB at 1080p)")
     ap.add_argument("--verify", type=int, default=8,
                     help="sessions whose last stream is compared with the CPU oracle after the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -168,9 +170,13 @@ class GlzWorkload:
         # buffer of the worst-case size (10 MB): do not ask for more sessions than the GPU has room for
         free = device_free_bytes(dist.local_rank)
         pool = max(1, min(args.pool, self.S))
+        self.cap = gpu.L.spice_gpu_glz_out_bound(B.LZ_IMAGE_TYPE_RGB32, W, H)
+        if getattr(args, "out_mb", 0) and not args.sim:
+            self.cap = min(self.cap, int(args.out_mb * (1 << 20)))
         if free:
             pool_bytes = pool * self.nframes * W * H * 4
-            fit = int((free - pool_bytes - (4 << 30)) // (96 << 20))
+            per_session = geo.window * 4 + geo.window // 4 + (8 << 20) + (1 << 20) + self.cap
+            fit = int((free - pool_bytes - (6 << 30)) // per_session)
             if fit < self.S:
                 print("bench: %d sessions do not fit %.0f GB of free device memory, running %d"
                       % (self.S, free / 1e9, max(1, fit)), file=sys.stderr, flush=True)
@@ -192,7 +198,6 @@ class GlzWorkload:
         self.pool = pool
         self.dicts = [B.GlzDictionary(gpu, geo.window, 1) for _ in range(self.S)]
         self.encs = [B.GlzEncoder(gpu, d, 0) for d in self.dicts]
-        self.cap = gpu.L.spice_gpu_glz_out_bound(B.LZ_IMAGE_TYPE_RGB32, W, H)
         self.outs = [gpu.malloc(self.cap) for _ in range(self.S)]
         # the job array is built once; a step only swaps in every session's next frame
         self.plan = B.GlzBatchPlan(gpu, [self.job(s, 0) for s in range(self.S)])
@@ -225,7 +230,8 @@ class GlzWorkload:
                             "dictionary window per session (BASELINE configs[1])",
                 "sessions_per_gpu": self.S, "sessions_requested": self.args.sessions,
                 "frames_per_session": self.args.steps,
-                "distinct_sequences_per_gpu": self.pool, "parallelism": "session-sharded"}
+                "distinct_sequences_per_gpu": self.pool, "out_buffer_bytes_per_session": self.cap,
+                "parallelism": "session-sharded"}
 
     def roofline(self, times, steps, out_bytes_timed):
         launches, ms = times.get("glz_parse_kernel", (0, 0.0))
@@ -378,6 +384,7 @@ class GlzWorkload:
         for fr in self.dev_frames:
             for f in fr:
                 self.gpu.free(f)
+        self.encs, self.dicts, self.outs, self.dev_frames = [], [], [], []
 
 
 # ---------------------------------------------------------------- sessions64
@@ -586,9 +593,13 @@ class MjpegWorkload:
     def close(self):
         for o in self.outs:
             self.gpu.free(o)
+        self.outs = []
+
+    def free_frames(self):
         if self.owns:
             for f in self.dev_frames:
                 self.gpu.free(f)
+            self.dev_frames = []
 
 
 # ------------------------------------------------------------------ multimon
@@ -795,6 +806,7 @@ def measure(cls, gpu, dist, args, geo, steps, warmup, e2e=True, cpu=True, **kw):
     part = {"workload": wl.config()["workload"], "value": round(units / dt / 1e6, 1), "unit": "Mpixels/s",
             "ms_per_step": round(dt / steps * 1e3, 3), "scaling": wl.scaling, "config": wl.config()}
     extra = wl.after_timed() if hasattr(wl, "after_timed") else {}
+    wl.close()          # the end-to-end pass below brings its own device state
     if dist.rank == 0:
         part["compression"] = {"images": int(sum(g[0] for g in gathered)),
                                "orig_MB": round(sum(g[1] for g in gathered) / 1e6, 1),
@@ -856,7 +868,6 @@ def main():
         for k, v in part.items():
             if k not in result and k not in ("workload",):
                 result[k] = v
-    wl.close()
 
     if args.also and args.workload == "glz1080":
         also = {}
@@ -867,14 +878,12 @@ def main():
             w2, p2, _ = measure(MjpegWorkload, gpu, dist, args, geo, half, 1, e2e=False, dct=dct, quality=q,
                                 shared=mj)
             also[key] = p2
-            w2.close()
         if dist.rank == 0:
             also["graduality2160"] = graduality_line(gpu, mj, args)
-        mj.close()
+        mj.free_frames()
         for key, cls in (("sessions64", Sessions64Workload), ("multimon", MultimonWorkload)):
             w3, p3, _ = measure(cls, gpu, dist, args, geo, half, 1, e2e=False, cpu=False)
             also[key] = p3
-            w3.close()
         if dist.rank == 0:
             for p in also.values():
                 p.pop("config", None)

@@ -516,9 +516,25 @@ struct GlzShared {
     uint32_t op;                       /* next byte */
     uint32_t copy;                     /* literals in the open count byte's run, 0 = none open */
     uint32_t last_copy;                /* where that count byte is */
+#ifdef GLZ_STAMPS
+    long long st_fast, st_gen, st_ngen;
+#endif
 };
 
 __shared__ GlzShared glz_sh;
+#ifdef GLZ_STAMPS
+__device__ unsigned long long glz_stamp_acc[16];
+extern "C" void spice_gpu_debug_stamps(unsigned long long *out, int reset)
+{
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(glz_stamp_acc), sizeof(unsigned long long) * 16);
+    if (reset) {
+        unsigned long long z[16] = {0};
+        hipMemcpyToSymbol(HIP_SYMBOL(glz_stamp_acc), z, sizeof(z));
+    }
+}
+#define STAMP() clock64()
+#endif
 
 __device__ __forceinline__ const GLZ_GLOBAL uint8_t *glz_arena(const GlzDevJob &job)
 {
@@ -1243,7 +1259,13 @@ __device__ __forceinline__ void glz_window_resolve(const GlzDevJob &job, uint32_
 
         while (l < 64) {
             /* ordinary stops: everything needed is in the quarter word */
+#ifdef GLZ_STAMPS
+            const long long f0 = STAMP();
+#endif
             glz_fast_stops(W, l, ins, stops, ms, last_len);
+#ifdef GLZ_STAMPS
+            sh.st_fast += STAMP() - f0;
+#endif
             if (l >= 64) {
                 break;
             }
@@ -1256,8 +1278,15 @@ __device__ __forceinline__ void glz_window_resolve(const GlzDevJob &job, uint32_
             {
                 const uint64_t bit = 1ull << l;
                 bool run;
+#ifdef GLZ_STAMPS
+                const long long g0 = STAMP();
+#endif
                 const int len = glz_resolve_general<MODE>(job, base, ip, ip_bound, Q * 64 + l, ins, vfl, q0, q1,
                                                           q2, q3, lane, &run);
+#ifdef GLZ_STAMPS
+                sh.st_gen += STAMP() - g0;
+                sh.st_ngen++;
+#endif
                 slow |= bit;
                 stops |= bit;
                 ins |= run ? 0ull : bit;
@@ -1541,24 +1570,58 @@ __device__ __forceinline__ void glz_parse_seg(const GlzDevJob &job, uint32_t seg
     const int ip_limit = npix - 6;
     int ip = from;
 
+#ifdef GLZ_STAMPS
+    long long a_tile = 0, a_scan = 0, a_res = 0, a_emit = 0, a_win = 0;
+    if (tid == 0) {
+        sh.st_fast = sh.st_gen = sh.st_ngen = 0;
+    }
+#endif
     while (ip < ip_limit) {
+#ifdef GLZ_STAMPS
+        const long long t0 = STAMP();
+#endif
         for (int t = tid; t < GLZ_TILE; t += GLZ_THREADS) {
             const int pos = ip - 1 + t;
             sh.tile[t] = (pos >= 0 && pos < npix) ? glz_load_px<MODE>(base, pos) : 0u;
         }
         __syncthreads();
+#ifdef GLZ_STAMPS
+        const long long t1 = STAMP();
+#endif
         uint32_t my_h;
         bool my_hv;
         glz_window_scan<MODE>(job, cs, seg_idx, base, ip, npix, tid, my_h, my_hv);
         __syncthreads();
+#ifdef GLZ_STAMPS
+        const long long t2 = STAMP();
+#endif
         if (w0) {
             glz_window_resolve<MODE>(job, seg_idx, base, ip, npix, lane);
         }
         __syncthreads();
+#ifdef GLZ_STAMPS
+        const long long t3 = STAMP();
+#endif
         glz_window_emit<MODE>(job, seg_idx, ip, tid, my_h, my_hv);
         __syncthreads();
+#ifdef GLZ_STAMPS
+        const long long t4 = STAMP();
+        a_tile += t1 - t0; a_scan += t2 - t1; a_res += t3 - t2; a_emit += t4 - t3; a_win++;
+#endif
         ip = sh.next_ip;
     }
+#ifdef GLZ_STAMPS
+    if (tid == 0) {
+        atomicAdd(&glz_stamp_acc[0], (unsigned long long)a_tile);
+        atomicAdd(&glz_stamp_acc[1], (unsigned long long)a_scan);
+        atomicAdd(&glz_stamp_acc[2], (unsigned long long)a_res);
+        atomicAdd(&glz_stamp_acc[3], (unsigned long long)a_emit);
+        atomicAdd(&glz_stamp_acc[4], (unsigned long long)a_win);
+        atomicAdd(&glz_stamp_acc[5], (unsigned long long)sh.st_fast);
+        atomicAdd(&glz_stamp_acc[6], (unsigned long long)sh.st_gen);
+        atomicAdd(&glz_stamp_acc[7], (unsigned long long)sh.st_ngen);
+    }
+#endif
 
     /* ---- leftovers as literals, then the run closes; glz_encode_tmpl.c:466-487 */
     if (w0) {
