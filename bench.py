@@ -51,7 +51,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="glz1080", choices=WORKLOADS)
-    ap.add_argument("--sessions", type=int, default=2048, help="GLZ display sessions per GPU")
+    ap.add_argument("--sessions", type=int, default=3072, help="GLZ display sessions per GPU")
     ap.add_argument("--frames", type=int, default=16, help="MJPEG frames per step per GPU")
     ap.add_argument("--clients", type=int, default=8, help="multimon: four-monitor clients per GPU")
     ap.add_argument("--pool", type=int, default=256, help="distinct synthetic desktop sequences per GPU")

@@ -96,7 +96,11 @@ struct Encoder {
     GlzEncoderUsrContext *usr;
     uint8_t id;
     Dict *dict;
-    DevBuffer out;       /* compressed stream of the synchronous path */
+    /* the synchronous path (glz_encode): a stream of its own, so that worker
+     * threads with different dictionaries run side by side on the device */
+    hipStream_t st = nullptr;
+    Staging staging;     /* job record and result */
+    DevBuffer out;       /* compressed stream */
     PinnedBuffer bounce; /* its host landing zone */
 };
 
@@ -164,7 +168,7 @@ void mark_image_dirty(Dict *d, HostImage *im);
  * window's size and is re-made to that bound the first time an image does not
  * fit: live images move to the front of the new arena in window order (their
  * segments' offsets change and are uploaded again with the next job). */
-bool arena_regrow(Dict *d, uint64_t need)
+bool arena_regrow(Dict *d, uint64_t need, hipStream_t st)
 {
     uint64_t live = 0;
     for (HostImage *im = d->used_images_head; im; im = im->next) {
@@ -181,7 +185,6 @@ bool arena_regrow(Dict *d, uint64_t need)
     if (!check(hipMalloc((void **)&fresh, cap + 64), "hipMalloc arena")) {
         return false;
     }
-    hipStream_t st = stream();
     uint64_t pos = 0;
     bool ok = true;
     for (HostImage *im = d->used_images_head; im && ok; im = im->next) {
@@ -269,7 +272,7 @@ void release_all_images(Dict *d)
     d->used_images_tail = nullptr;
 }
 
-bool ensure_dev_segs(Dict *d)
+bool ensure_dev_segs(Dict *d, hipStream_t st)
 {
     uint32_t need = (uint32_t)d->segs.size();
     if (need <= d->d_segs_cap) {
@@ -279,7 +282,6 @@ bool ensure_dev_segs(Dict *d)
     if (!check(hipMalloc((void **)&n, sizeof(GlzDevSeg) * (size_t)need), "hipMalloc segs")) {
         return false;
     }
-    hipStream_t st = stream();
     bool ok = check(hipMemsetAsync(n, 0, sizeof(GlzDevSeg) * (size_t)need, st), "memset segs");
     if (ok && d->d_segs) {
         ok = check(hipMemcpyAsync(n, d->d_segs, sizeof(GlzDevSeg) * (size_t)d->d_segs_cap,
@@ -507,7 +509,7 @@ const char *validate(LzImageType type, int width, int height, int stride)
  * description.  Called with the dictionary locked. */
 const char *prepare(Encoder *enc, LzImageType type, int width, int height, int top_down,
                     int stride, const std::vector<Chunk> &chunks, GlzUsrImageContext *usr_context,
-                    uint8_t *d_out, uint32_t out_cap, bool device_src, Prepared *p)
+                    uint8_t *d_out, uint32_t out_cap, bool device_src, hipStream_t st, Prepared *p)
 {
     Dict *d = enc->dict;
     d->cur_usr = enc->usr;
@@ -543,7 +545,7 @@ const char *prepare(Encoder *enc, LzImageType type, int width, int height, int t
         }
     }
     uint64_t at = 0;
-    if (!ring_alloc(d, need, &at) && !(arena_regrow(d, need) && ring_alloc(d, need, &at))) {
+    if (!ring_alloc(d, need, &at) && !(arena_regrow(d, need, st) && ring_alloc(d, need, &at))) {
         return "window arena exhausted\n";
     }
 
@@ -608,7 +610,7 @@ const char *prepare(Encoder *enc, LzImageType type, int width, int height, int t
         head_dist = 0;
     }
 
-    if (!ensure_dev_segs(d)) {
+    if (!ensure_dev_segs(d, st)) {
         /* the image is in the window already: it must never be referenced */
         im->alive = false;
         post_encode(d, enc->id);
@@ -709,7 +711,7 @@ Flight g_flight;
  * them and enqueues copy + parse.  copy_on_device: the chunk sources are
  * device pointers (batch path); otherwise the caller has already enqueued
  * host-to-arena copies on the stream. */
-bool launch(Prepared *jobs, size_t n, Staging &st, size_t *results_off, bool copy_on_device)
+bool launch(Prepared *jobs, size_t n, Staging &st, size_t *results_off, bool copy_on_device, hipStream_t s)
 {
     size_t off_jobs = 0;
     size_t off_u32 = off_jobs + sizeof(GlzDevJob) * n;
@@ -761,7 +763,6 @@ bool launch(Prepared *jobs, size_t n, Staging &st, size_t *results_off, bool cop
         }
         dj[pos] = p.dev;
     }
-    hipStream_t s = stream();
     if (!check(hipMemcpyAsync(st.dev, st.host, off_res, hipMemcpyHostToDevice, s), "upload jobs")) {
         return false;
     }
@@ -847,7 +848,7 @@ GlzEncDictContext *glz_enc_dictionary_create(uint32_t size, uint32_t max_encoder
     d->arena_cap = (uint64_t)size * 4ull + arena_slack(size);
     bool ok = check(hipMalloc((void **)&d->d_arena, d->arena_cap + 64), "hipMalloc arena") &&
               check(hipMalloc((void **)&d->d_htab, sizeof(uint2) * (size_t)GLZ_HASH_SIZE), "hipMalloc htab");
-    ok = ok && ensure_dev_segs(d);
+    ok = ok && ensure_dev_segs(d, stream());
     if (!ok || !dict_reset(d)) {
         dict_free_device(d);
         delete d;
@@ -1008,10 +1009,17 @@ GlzEncoderContext *glz_encoder_create(uint8_t id, GlzEncDictContext *dictionary,
     if (!d || id >= d->max_encoders) {
         return nullptr;
     }
+    if (!ensure_init()) {
+        return nullptr;
+    }
     Encoder *e = new Encoder();
     e->usr = usr;
     e->id = id;
     e->dict = d;
+    if (!check(hipStreamCreateWithFlags(&e->st, hipStreamNonBlocking), "hipStreamCreate")) {
+        delete e;
+        return nullptr;
+    }
     return (GlzEncoderContext *)e;
 }
 
@@ -1021,6 +1029,11 @@ void glz_encoder_destroy(GlzEncoderContext *opaque_encoder)
     if (!e) {
         return;
     }
+    if (e->st) {
+        hipStreamSynchronize(e->st);
+        hipStreamDestroy(e->st);
+    }
+    e->staging.release();
     e->out.release();
     e->bounce.release();
     delete e;
@@ -1073,12 +1086,10 @@ int glz_encode(GlzEncoderContext *opaque_encoder, LzImageType type, int width, i
         }
     }
 
+    /* the dictionary's lock is all this call needs: it works on the encoder's own
+     * stream and buffers, so encoders of different dictionaries do not wait for
+     * each other (a batch in flight holds the locks of its dictionaries) */
     std::lock_guard<std::recursive_mutex> dict_lock(d->lock);
-    GateHold dev_lock("glz_encode");
-    if (!dev_lock.ok) {
-        usr_error(enc->usr, "a batch of this thread is in flight\n");
-        return 0;
-    }
 
     size_t bound = spice_gpu_glz_out_bound(type, width, height);
     if (!enc->out.reserve(bound) || !enc->bounce.reserve(bound)) {
@@ -1087,7 +1098,7 @@ int glz_encode(GlzEncoderContext *opaque_encoder, LzImageType type, int width, i
     }
     std::vector<Prepared> jobs(1);
     const char *err = prepare(enc, type, width, height, top_down, stride, chunks, usr_context,
-                              enc->out.ptr, (uint32_t)bound, false, &jobs[0]);
+                              enc->out.ptr, (uint32_t)bound, false, enc->st, &jobs[0]);
     if (err) {
         usr_error(enc->usr, err);
         return 0;
@@ -1096,14 +1107,14 @@ int glz_encode(GlzEncoderContext *opaque_encoder, LzImageType type, int width, i
         *o_enc_dict_context = (GlzEncDictImageContext *)jobs[0].image;
     }
 
-    hipStream_t s = stream();
-    static Staging staging;
+    hipStream_t s = enc->st;
+    Staging &staging = enc->staging;
     size_t res_off = 0;
     bool ok = true;
     for (const GlzCopyDesc &c : jobs[0].copies) {
         ok = ok && check(hipMemcpyAsync(c.dst, c.src, c.bytes, hipMemcpyHostToDevice, s), "upload rows");
     }
-    ok = ok && launch(jobs.data(), 1, staging, &res_off, false);
+    ok = ok && launch(jobs.data(), 1, staging, &res_off, false, s);
     ok = ok && check(hipStreamSynchronize(s), "glz sync");
     int32_t size = ok ? *(int32_t *)(staging.host + res_off) : 0;
     if (ok && size > 0) {
@@ -1257,7 +1268,7 @@ int spice_gpu_glz_submit(SpiceGpuGlzJob *jobs, int njobs)
             }
             const char *err = prepare((Encoder *)job.encoder, job.type, job.width, job.height,
                                       job.top_down, job.stride, chunks, job.usr_context,
-                                      (uint8_t *)job.out, job.out_capacity, true, &p);
+                                      (uint8_t *)job.out, job.out_capacity, true, stream(), &p);
             if (err) {
                 set_error("glz batch job %d: %s", j, err);
                 p.reset();
@@ -1267,7 +1278,7 @@ int spice_gpu_glz_submit(SpiceGpuGlzJob *jobs, int njobs)
             job.dict_image = (GlzEncDictImageContext *)p.image;
         }
         if (ok) {
-            ok = launch(lv.jobs.data(), lv.idx.size(), lv.staging, &lv.results_off, true);
+            ok = launch(lv.jobs.data(), lv.idx.size(), lv.staging, &lv.results_off, true, stream());
             done = lv.idx.size();
         }
         if (ok) {

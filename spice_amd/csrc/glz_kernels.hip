@@ -1209,7 +1209,14 @@ __device__ __forceinline__ int glz_resolve_general(const GlzDevJob &job, const G
                 len = glz_match_len<MODE>(base, anchor, rbase, ref, len, maxn, lane);
             }
         } else if (maxed) {
-            len = glz_match_len<MODE>(base, anchor, base, ip + cand, len, ip_bound - anchor, lane);
+            /* a candidate inside the window: both sides are in the LDS tile as far
+             * as it reaches, and most of these matches end a few pixels on */
+            const int maxn = ip_bound - anchor;
+            int checked = 0;
+            len = glz_tile_match_len<MODE>(sh.tile, i, cand, maxn, lane, &checked);
+            if (len == checked && checked < maxn) {
+                len = glz_match_len<MODE>(base, anchor, base, ip + cand, len, maxn, lane);
+            }
         }
     }
     len = (int)glz_uniform((uint32_t)len); /* every lane holds the same value already */

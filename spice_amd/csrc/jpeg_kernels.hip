@@ -510,8 +510,17 @@ __device__ __forceinline__ void jpeg_load_tiles_wide(const JpegDevJob &job, uint
     }
 }
 
-/* Always inlined: the kernel's register limit (JPEG_FOUR_PER_CU) is an attribute of
- * the kernel function and would not reach this body if it were called. */
+/* Always inlined.  One development build, in which the compiler had emitted this body
+ * as a call, took a memory access fault on the GPU; forcing the inline removed it.  The
+ * first explanation -- the callee not being held to the kernel's register limit
+ * (JPEG_FOUR_PER_CU) -- does not stand: rebuilt as a call (noinline, hipcc of ROCm 7.2,
+ * gfx950) the callee stays within v0..v127, because a function without attributes is
+ * compiled for work-groups of up to 1024 lanes = four waves per SIMD, this kernel's own
+ * budget, and the kernel's descriptor covers the callee (.vgpr_count 128,
+ * .private_segment_fixed_size 256 for the callee-saved v40..v127, LDS 38 936 B).  A
+ * callee over budget would lower the occupancy, not fault.  The faulting source itself
+ * (an intermediate state of the Huffman walk) was never committed, so its fault is not
+ * explained; what is shipped has no call in either strip kernel. */
 template <bool IFAST>
 __device__ __forceinline__ void jpeg_strip_body(const JpegDevJob &job, const uint32_t *huff_g, int group)
 {

@@ -207,10 +207,13 @@ void timing_collect_locked()
             continue;
         }
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
-            g_time_acc[(size_t)t.name_id].launches++;
-            g_time_acc[(size_t)t.name_id].total_ms += (double)ms;
+        if (hipEventElapsedTime(&ms, t.a, t.b) != hipSuccess) {
+            (void)hipGetLastError();
+            open.push_back(t); /* on another thread's stream and not finished yet */
+            continue;
         }
+        g_time_acc[(size_t)t.name_id].launches++;
+        g_time_acc[(size_t)t.name_id].total_ms += (double)ms;
         g_event_pool.push_back(t.a);
         g_event_pool.push_back(t.b);
     }

@@ -13,6 +13,7 @@
 #include <unistd.h>
 
 #include <map>
+#include <mutex>
 #include <vector>
 
 sim_uint3 threadIdx, blockIdx;
@@ -196,6 +197,9 @@ static void sim_on_segv(int, siginfo_t *si, void *)
 
 void sim_run_grid(dim3 grid, dim3 block, const std::function<void()> &body)
 {
+    /* one grid at a time: the fibers and their scheduler are process-wide */
+    static std::mutex grid_mutex;
+    std::lock_guard<std::mutex> one_grid(grid_mutex);
     static bool handler_installed = false;
     if (!handler_installed) {
         static char alt_stack[64 * 1024];
@@ -281,6 +285,8 @@ size_t page_size()
 }
 } // namespace
 
+static std::mutex allocs_mutex; /* worker threads allocate side by side */
+
 hipError_t hipMalloc(void **out, size_t n)
 {
     size_t pg = page_size();
@@ -295,6 +301,7 @@ hipError_t hipMalloc(void **out, size_t n)
     mprotect(m + pg + pages, pg, PROT_NONE);
     char *p = m + pg + pages - body; /* the end of the buffer touches the guard page */
     memset(p, 0xcd, body);
+    std::lock_guard<std::mutex> lk(allocs_mutex);
     allocs[p] = Alloc{m, len};
     *out = p;
     return hipSuccess;
@@ -305,6 +312,7 @@ hipError_t hipFree(void *p)
     if (!p) {
         return hipSuccess;
     }
+    std::lock_guard<std::mutex> lk(allocs_mutex);
     auto it = allocs.find(p);
     if (it == allocs.end()) {
         return hipErrorInvalidValue;

@@ -142,3 +142,52 @@ def test_sim_arena_regrow(sim, oracle):
 @pytest.mark.gpu
 def test_gpu_arena_regrow(gpu, oracle):
     run_arena_regrow(gpu, oracle)
+
+
+def run_worker_threads(dev, oracle, nthreads=4, nimages=6):
+    """RedWorker threads, one per display, each with its own dictionary and encoder, call
+    glz_encode at the same time (one worker thread per QXL device,
+    server/red_dispatcher.c:1148): every stream must be the one the oracle makes for that
+    display alone."""
+    import threading
+    w, h = 160, 64
+    per = [images(nimages, 200 + 10 * t, w, h)[0] for t in range(nthreads)]
+    gds = [B.GlzDictionary(dev, 30000, 1) for _ in range(nthreads)]
+    ges = [B.GlzEncoder(dev, d, 0) for d in gds]
+    got = [[] for _ in range(nthreads)]
+    errs = []
+
+    def work(t):
+        try:
+            for px in per[t]:
+                got[t].append(ges[t].encode(T32, w, h, w * 4, [px])[0])
+        except Exception as e:              # noqa: BLE001 - reported below
+            errs.append((t, e))
+
+    ths = [threading.Thread(target=work, args=(t,)) for t in range(nthreads)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    try:
+        assert not errs, errs
+        for t in range(nthreads):
+            od = oracle.GlzDict(30000, 1)
+            for k, px in enumerate(per[t]):
+                want, _ = od.encode(T32, w, h, w * 4, [px])
+                assert_same_stream(want, got[t][k], "thread %d image %d" % (t, k))
+            od.close()
+    finally:
+        for e in ges:
+            e.close()
+        for d in gds:
+            d.close()
+
+
+def test_sim_worker_threads(sim, oracle):
+    run_worker_threads(sim, oracle)
+
+
+@pytest.mark.gpu
+def test_gpu_worker_threads(gpu, oracle):
+    run_worker_threads(gpu, oracle, nthreads=8, nimages=10)

@@ -19,6 +19,27 @@ for f in fr:
     s, _ = e.encode(B.LZ_IMAGE_TYPE_RGB32, W, H, W * 4, [f])
     ts.append(time.perf_counter() - t)
 print("glz_encode 1080p: ms per call", [round(x * 1e3, 1) for x in ts], "-> %.0f Mpx/s" % (W * H / np.median(ts[1:]) / 1e6))
+# worker threads, one display each (server/red_dispatcher.c:1148), calling glz_encode side by side
+import threading
+for nth in (2, 4, 8, 16):
+    seqs = [frames.DesktopSequence(W, H, seed=300 + t) for t in range(nth)]
+    frs = [[q.next().reshape(H, -1) for _ in range(6)] for q in seqs]
+    ds = [B.GlzDictionary(gpu, 16 << 20, 1) for _ in range(nth)]
+    es = [B.GlzEncoder(gpu, x, 0) for x in ds]
+    for t in range(nth):
+        es[t].encode(B.LZ_IMAGE_TYPE_RGB32, W, H, W * 4, [frs[t][0]])
+    def work(t):
+        for f in frs[t][1:]:
+            es[t].encode(B.LZ_IMAGE_TYPE_RGB32, W, H, W * 4, [f])
+    ths = [threading.Thread(target=work, args=(t,)) for t in range(nth)]
+    t0 = time.perf_counter()
+    for th in ths: th.start()
+    for th in ths: th.join()
+    dt = time.perf_counter() - t0
+    print("glz_encode 1080p, %d worker threads: %.1f ms per frame per thread, %.0f Mpx/s in all"
+          % (nth, dt / 5 * 1e3, nth * 5 * W * H / dt / 1e6), flush=True)
+    for x in es: x.close()
+    for x in ds: x.close()
 W, H = 3840, 2160
 vs = frames.VideoSequence(W, H, seed=7)
 vf = [vs.next().reshape(H, -1) for _ in range(5)]
