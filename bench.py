@@ -94,14 +94,14 @@ class Geometry:
             self.w2160, self.h2160 = 3840, 2160
 
 
-def pmc_traffic(workload, key, value):
+def pmc_traffic(workload, **same):
     """HBM bytes per launch of the workload's dominant kernel, from the PMC passes kept under
     profiles/ (rocprofv3 cannot run inside this process); None when they were taken on another
     configuration."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             t = json.load(f)[workload]
-        return int(t["traffic_bytes"]) if t.get(key) == value else None
+        return int(t["traffic_bytes"]) if all(t.get(k) == v for k, v in same.items()) else None
     except (OSError, KeyError, ValueError):
         return None
 
@@ -242,7 +242,8 @@ class GlzWorkload:
         # and reference traffic is not counted.
         alg = self.S * self.W * self.H * 4 + out_bytes_timed / max(1, steps)
         r = roofline_of("glz_parse_kernel", alg, launches, ms,
-                        traffic=pmc_traffic(self.name, "distinct_sequences_per_gpu", self.pool))
+                        traffic=pmc_traffic(self.name, sessions_per_gpu=self.S,
+                                            distinct_sequences_per_gpu=self.pool))
         cl, cms = times.get("glz_copy_kernel", (0, 0.0))
         if cl:
             calg = self.S * self.W * self.H * 8
@@ -261,6 +262,8 @@ class GlzWorkload:
         from oracle import oracle as O
         np, B = self.np, self.B
         extra = {"host_us_per_step": round(float(np.mean(self.host_us[self.args.warmup:])), 1)}
+        if not self.verify_seqs:          # --verify 0: nothing beyond the timed launches (profiling runs)
+            return extra
         self.step()
         nver = 0
         for p in self.verify_seqs:
@@ -491,7 +494,7 @@ class MjpegWorkload:
         alg = self.F * self.W * self.H * 4 + out_bytes_timed / max(1, steps)
         main = self.dct and self.quality == 70
         r = roofline_of(self.kernel, alg, launches, ms,
-                        traffic=pmc_traffic("mjpeg2160", "frames_per_step_per_gpu", self.F) if main else None)
+                        traffic=pmc_traffic("mjpeg2160", frames_per_step_per_gpu=self.F) if main else None)
         # offsets + gather + finish, timed as one group
         tail = times.get("jpeg_bitstream_kernels", (0, 0.0))[1]
         r["bitstream_kernels_ms_per_launch"] = round(tail / launches, 3)

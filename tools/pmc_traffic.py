@@ -1,7 +1,7 @@
 """Per-launch HBM traffic of the dominant kernels from two rocprofv3 PMC passes
 (FETCH_SIZE, WRITE_SIZE), written into profiles/traffic.json.
 
-usage: pmc_traffic.py FETCH_counter_collection.csv WRITE_counter_collection.csv WARMUP SESSIONS
+usage: pmc_traffic.py FETCH_counter_collection.csv WRITE_counter_collection.csv WARMUP SESSIONS POOL
 Counter values are KiB per XCD instance and are summed per dispatch; the first
 WARMUP dispatches of each kernel are dropped (bench.py's untimed steps)."""
 import collections
@@ -38,5 +38,6 @@ for k, name in KERNELS.items():
         doc[name].update(fetch_bytes_raw=fetch[k], write_bytes=write[k],
                          traffic_bytes=int(2 * fetch[k] + write[k]))
 doc["glz1080"]["sessions_per_gpu"] = int(sys.argv[4])
+doc["glz1080"]["distinct_sequences_per_gpu"] = int(sys.argv[5])
 json.dump(doc, open(path, "w"), indent=1)
 print(json.dumps(doc, indent=1))
