@@ -17,6 +17,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
 #include <memory>
 #include <mutex>
 #include <vector>
@@ -691,6 +693,7 @@ void abandon(Prepared &p)
 struct Level {
     std::vector<int> idx;       /* the caller's job numbers, ascending */
     std::vector<Prepared> jobs; /* same order */
+    std::vector<Prepared *> ptrs;
     Staging staging;
     size_t results_off = 0;
 };
@@ -711,13 +714,13 @@ Flight g_flight;
  * them and enqueues copy + parse.  copy_on_device: the chunk sources are
  * device pointers (batch path); otherwise the caller has already enqueued
  * host-to-arena copies on the stream. */
-bool launch(Prepared *jobs, size_t n, Staging &st, size_t *results_off, bool copy_on_device, hipStream_t s)
+bool launch(Prepared *const *jobs, size_t n, Staging &st, size_t *results_off, bool copy_on_device, hipStream_t s)
 {
     size_t off_jobs = 0;
     size_t off_u32 = off_jobs + sizeof(GlzDevJob) * n;
     size_t n_u32 = 0, n_upd = 0, n_copy = 0;
     for (size_t j = 0; j < n; j++) {
-        const Prepared &p = jobs[j];
+        const Prepared &p = *jobs[j];
         n_u32 += p.seg_list.size();
         n_upd += p.updates.size();
         n_copy += p.copies.size();
@@ -745,13 +748,13 @@ bool launch(Prepared *jobs, size_t n, Staging &st, size_t *results_off, bool cop
     std::vector<double> cost(n);
     for (size_t j = 0; j < n; j++) {
         order[j] = (uint32_t)j;
-        cost[j] = (double)jobs[j].raw_bytes * (jobs[j].enc ? jobs[j].enc->dict->cost_hint : 1.0);
+        cost[j] = (double)jobs[j]->raw_bytes * (jobs[j]->enc ? jobs[j]->enc->dict->cost_hint : 1.0);
     }
     std::stable_sort(order.begin(), order.end(),
                      [&cost](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
     for (size_t pos = 0; pos < n; pos++) {
         const size_t j = order[pos];
-        Prepared &p = jobs[j];
+        Prepared &p = *jobs[j];
         p.dev.seg_list_off = (uint32_t)iu;
         p.dev.upd_off = (uint32_t)iup;
         p.dev.result = (int32_t *)(st.dev + off_res) + j;
@@ -771,7 +774,7 @@ bool launch(Prepared *jobs, size_t n, Staging &st, size_t *results_off, bool cop
      * for them at the end, so whoever synchronises it has both. */
     bool beside = copy_on_device && n_copy != 0;
     for (size_t j = 0; j < n; j++) {
-        beside = beside && jobs[j].dev.own_src != nullptr;
+        beside = beside && jobs[j]->dev.own_src != nullptr;
     }
     uint64_t per_block = 256ull * 16 * 8; /* 8 vectors per lane */
     unsigned blocks = (unsigned)((max_copy + per_block - 1) / per_block);
@@ -784,7 +787,7 @@ bool launch(Prepared *jobs, size_t n, Staging &st, size_t *results_off, bool cop
     }
     unsigned type_mask = 0;
     for (size_t j = 0; j < n; j++) {
-        type_mask |= 1u << jobs[j].dev.type;
+        type_mask |= 1u << jobs[j]->dev.type;
     }
     glz_launch_parse((const GlzDevJob *)(st.dev + off_jobs), (int)n, type_mask,
                      (const uint32_t *)(st.dev + off_u32),
@@ -813,6 +816,91 @@ bool launch(Prepared *jobs, size_t n, Staging &st, size_t *results_off, bool cop
     }
     *results_off = off_res;
     return true;
+}
+
+/* Worker threads that call glz_encode at about the same time (one RedWorker
+ * thread per display, server/red_dispatcher.c:1148) are served by one parse
+ * launch: every caller has prepared its image and uploaded its rows, queues the
+ * job, and the first one in becomes the round's leader, launches all queued
+ * jobs together on its encoder's stream and hands each caller its result.
+ * Callers that arrive while a round runs form the next round.  A device runs
+ * the kernels of few streams side by side (it has a handful of hardware
+ * queues), so separate launches from sixteen threads would mostly wait for one
+ * another; one launch has a workgroup per caller.  Every caller holds its own
+ * dictionary's lock meanwhile, so the jobs of a round are on distinct
+ * dictionaries. */
+struct Waiting {
+    Prepared *job;
+    int32_t size = 0;
+    bool ok = false;
+    bool done = false;
+};
+
+struct Combiner {
+    std::mutex m;
+    std::condition_variable cv;
+    std::vector<Waiting *> queue;
+    bool leader_active = false;
+    int entering = 0; /* callers that will queue a job shortly */
+};
+Combiner g_combiner;
+
+void combiner_enter()
+{
+    std::lock_guard<std::mutex> lk(g_combiner.m);
+    g_combiner.entering++;
+}
+
+void combiner_leave()
+{
+    std::lock_guard<std::mutex> lk(g_combiner.m);
+    g_combiner.entering--;
+    g_combiner.cv.notify_all();
+}
+
+/* Called by a thread that has counted itself in with combiner_enter().  Returns
+ * true with *size set when the job's stream is in its encoder's device buffer. */
+bool combiner_run(Encoder *enc, Prepared *job, int32_t *size)
+{
+    Combiner &c = g_combiner;
+    Waiting me;
+    me.job = job;
+    std::unique_lock<std::mutex> lk(c.m);
+    c.entering--;
+    c.queue.push_back(&me);
+    c.cv.notify_all();
+    while (!me.done) {
+        if (c.leader_active) {
+            c.cv.wait(lk);
+            continue;
+        }
+        /* lead this round: give the callers that are on their way a moment */
+        c.leader_active = true;
+        const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(3000);
+        while (c.entering > 0 && c.cv.wait_until(lk, until) != std::cv_status::timeout) {
+        }
+        std::vector<Waiting *> round;
+        round.swap(c.queue);
+        lk.unlock();
+        std::vector<Prepared *> ptrs;
+        for (Waiting *w : round) {
+            ptrs.push_back(w->job);
+        }
+        size_t res_off = 0;
+        bool ok = launch(ptrs.data(), ptrs.size(), enc->staging, &res_off, false, enc->st);
+        ok = check(hipStreamSynchronize(enc->st), "glz sync") && ok;
+        const int32_t *res = (const int32_t *)(enc->staging.host + res_off);
+        lk.lock();
+        for (size_t k = 0; k < round.size(); k++) {
+            round[k]->ok = ok;
+            round[k]->size = ok ? res[k] : 0;
+            round[k]->done = true;
+        }
+        c.leader_active = false;
+        c.cv.notify_all();
+    }
+    *size = me.size;
+    return me.ok;
 }
 
 void usr_error(GlzEncoderUsrContext *usr, const char *msg)
@@ -1090,6 +1178,17 @@ int glz_encode(GlzEncoderContext *opaque_encoder, LzImageType type, int width, i
      * stream and buffers, so encoders of different dictionaries do not wait for
      * each other (a batch in flight holds the locks of its dictionaries) */
     std::lock_guard<std::recursive_mutex> dict_lock(d->lock);
+    /* from here until the job is queued, a round's leader waits for this caller */
+    struct Entering {
+        bool counted = true;
+        Entering() { combiner_enter(); }
+        ~Entering()
+        {
+            if (counted) {
+                combiner_leave();
+            }
+        }
+    } entering;
 
     size_t bound = spice_gpu_glz_out_bound(type, width, height);
     if (!enc->out.reserve(bound) || !enc->bounce.reserve(bound)) {
@@ -1108,15 +1207,16 @@ int glz_encode(GlzEncoderContext *opaque_encoder, LzImageType type, int width, i
     }
 
     hipStream_t s = enc->st;
-    Staging &staging = enc->staging;
-    size_t res_off = 0;
     bool ok = true;
     for (const GlzCopyDesc &c : jobs[0].copies) {
         ok = ok && check(hipMemcpyAsync(c.dst, c.src, c.bytes, hipMemcpyHostToDevice, s), "upload rows");
     }
-    ok = ok && launch(jobs.data(), 1, staging, &res_off, false, s);
-    ok = ok && check(hipStreamSynchronize(s), "glz sync");
-    int32_t size = ok ? *(int32_t *)(staging.host + res_off) : 0;
+    ok = ok && check(hipStreamSynchronize(s), "upload rows");
+    int32_t size = 0;
+    if (ok) {
+        entering.counted = false; /* combiner_run counts this caller out itself */
+        ok = combiner_run(enc, &jobs[0], &size);
+    }
     if (ok && size > 0) {
         ok = check(hipMemcpyAsync(enc->bounce.ptr, enc->out.ptr, (size_t)size,
                                   hipMemcpyDeviceToHost, s), "download stream") &&
@@ -1278,7 +1378,11 @@ int spice_gpu_glz_submit(SpiceGpuGlzJob *jobs, int njobs)
             job.dict_image = (GlzEncDictImageContext *)p.image;
         }
         if (ok) {
-            ok = launch(lv.jobs.data(), lv.idx.size(), lv.staging, &lv.results_off, true, stream());
+            lv.ptrs.resize(lv.idx.size());
+            for (size_t k = 0; k < lv.idx.size(); k++) {
+                lv.ptrs[k] = &lv.jobs[k];
+            }
+            ok = launch(lv.ptrs.data(), lv.idx.size(), lv.staging, &lv.results_off, true, stream());
             done = lv.idx.size();
         }
         if (ok) {
