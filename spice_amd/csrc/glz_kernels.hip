@@ -518,22 +518,29 @@ struct GlzShared {
     uint32_t last_copy;                /* where that count byte is */
 #ifdef GLZ_STAMPS
     long long st_fast, st_gen, st_ngen;
+    long long st_scan[8];
+    long long st_emit[8];
 #endif
 };
 
 __shared__ GlzShared glz_sh;
 #ifdef GLZ_STAMPS
-__device__ unsigned long long glz_stamp_acc[16];
+__device__ unsigned long long glz_stamp_acc[24];
 extern "C" void spice_gpu_debug_stamps(unsigned long long *out, int reset)
 {
     hipDeviceSynchronize();
-    hipMemcpyFromSymbol(out, HIP_SYMBOL(glz_stamp_acc), sizeof(unsigned long long) * 16);
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(glz_stamp_acc), sizeof(unsigned long long) * 24);
     if (reset) {
-        unsigned long long z[16] = {0};
+        unsigned long long z[24] = {0};
         hipMemcpyToSymbol(HIP_SYMBOL(glz_stamp_acc), z, sizeof(z));
     }
 }
 #define STAMP() clock64()
+#define SCAN_STAMP(i) do { const long long n_ = STAMP(); if (tid == 0) sh.st_scan[i] += n_ - ss_; ss_ = n_; } while (0)
+#define EMIT_STAMP(i) do { const long long n_ = STAMP(); if (tid == 0) sh.st_emit[i] += n_ - es_; es_ = n_; } while (0)
+#else
+#define SCAN_STAMP(i) do { } while (0)
+#define EMIT_STAMP(i) do { } while (0)
 #endif
 
 __device__ __forceinline__ const GLZ_GLOBAL uint8_t *glz_arena(const GlzDevJob &job)
@@ -723,6 +730,9 @@ __device__ __forceinline__ void glz_window_scan(const GlzDevJob &job, const GlzD
 {
     typedef GlzTraits<MODE> T;
     GlzShared &sh = glz_sh;
+#ifdef GLZ_STAMPS
+    long long ss_ = STAMP();
+#endif
     const int ip_bound = npix - 2, ip_limit = npix - 6;
     const int p = tid, q = ip + p;
     const bool act = q < ip_limit;
@@ -756,12 +766,16 @@ __device__ __forceinline__ void glz_window_scan(const GlzDevJob &job, const GlzD
         }
     }
     __syncthreads();
+    SCAN_STAMP(0);
 
     uint32_t A = (act ? GLZ_A_ACT : 0u) | (rle ? GLZ_A_RLE : 0u);
     uint32_t B = 0;
     const int maxn = ip_bound - q;
 
-    /* (1) the two nearest earlier window positions with this hash */
+    /* (1) the two nearest earlier window positions with this hash.  (Reading the
+     * key's whole row into registers first and walking it there was measured and
+     * is slower: eight unrolled bit loops diverge worse than this one, and the row
+     * costs eight registers.) */
     int n1 = -1, n2 = -1;
     if (look) {
         for (int v = p >> 5; v >= 0 && n2 < 0; v--) {
@@ -784,6 +798,7 @@ __device__ __forceinline__ void glz_window_scan(const GlzDevJob &job, const GlzD
         }
     }
 
+    SCAN_STAMP(1);
     /* (2) the table's entry: validation and do_match's distance rules
      * (glz_encode_tmpl.c:147-229); its pixels are requested here and compared
      * in (4) */
@@ -828,6 +843,7 @@ __device__ __forceinline__ void glz_window_scan(const GlzDevJob &job, const GlzD
         }
     }
 
+    SCAN_STAMP(2);
     /* (3) the window candidates against the LDS tile */
     uint32_t mine[GLZ_K];
 #pragma unroll
@@ -861,6 +877,7 @@ __device__ __forceinline__ void glz_window_scan(const GlzDevJob &job, const GlzD
             (maxed ? GLZ_B_MAX2 : 0u);
     }
 
+    SCAN_STAMP(3);
     /* (4) the table's candidate */
     if (gok) {
         int len = 0;
@@ -885,6 +902,7 @@ __device__ __forceinline__ void glz_window_scan(const GlzDevJob &job, const GlzD
             sh.g_pdist[p] = gpdist;
         }
     }
+    SCAN_STAMP(4);
     if (rle) {
         /* glz_encode_tmpl.c:310-335: the run ends at the first pixel that
          * differs from its predecessor; B = its length, 0 when it leaves the
@@ -914,6 +932,7 @@ __device__ __forceinline__ void glz_window_scan(const GlzDevJob &job, const GlzD
     }
     sh.infoA[p] = A;
     sh.infoB[p] = B;
+    SCAN_STAMP(5);
 }
 
 /* stores of one match's tail (window positions t0, t1; -1 = none) that fall into quarter q */
@@ -1367,6 +1386,9 @@ __device__ __forceinline__ void glz_window_emit(const GlzDevJob &job, uint32_t s
 {
     typedef GlzTraits<MODE> T;
     GlzShared &sh = glz_sh;
+#ifdef GLZ_STAMPS
+    long long es_ = STAMP();
+#endif
     const int lane = tid & 63, p = tid;
     const int w = (int)glz_uniform((uint32_t)(tid >> 6));
     const uint64_t lit0 = glz_uniform64(sh.lit[0]), lit1 = glz_uniform64(sh.lit[1]);
@@ -1402,6 +1424,7 @@ __device__ __forceinline__ void glz_window_emit(const GlzDevJob &job, uint32_t s
         }
     }
 
+    EMIT_STAMP(0);
     /* (2) where this wavefront's 64 positions stand in the literal runs */
     uint32_t carry = c0;     /* literals of the open run before this wavefront's positions */
     bool nomatch = true;     /* ... and no match starts before them in the window */
@@ -1468,6 +1491,7 @@ __device__ __forceinline__ void glz_window_emit(const GlzDevJob &job, uint32_t s
         }
     }
 
+    EMIT_STAMP(1);
     uint32_t bytes = 0, elen = 0, idist = 0, pdist = 0, nff = 0;
     bool cs = false;
     if (is_lit) {
@@ -1511,6 +1535,7 @@ __device__ __forceinline__ void glz_window_emit(const GlzDevJob &job, uint32_t s
         nff = elen >= 7 ? (elen - 7) / 255u : 0;
     }
 
+    EMIT_STAMP(2);
     /* (3) byte offsets: prefix sum over the 256 positions */
     uint32_t incl = bytes;
 #pragma unroll
@@ -1525,6 +1550,7 @@ __device__ __forceinline__ void glz_window_emit(const GlzDevJob &job, uint32_t s
     const uint32_t ws0 = sh.wave_sum[0], ws1 = sh.wave_sum[1], ws2 = sh.wave_sum[2], ws3 = sh.wave_sum[3];
     uint32_t off = op_in + incl - bytes + (w > 0 ? ws0 : 0u) + (w > 1 ? ws1 : 0u) + (w > 2 ? ws2 : 0u);
 
+    EMIT_STAMP(3);
     /* (4) write */
     if (is_lit) {
         if (cs) {
@@ -1560,6 +1586,7 @@ __device__ __forceinline__ void glz_window_emit(const GlzDevJob &job, uint32_t s
     if (my_hv) {
         sh.bitmap[(my_h & (GLZ_KEYS - 1)) * 8 + (p >> 5)] = 0;
     }
+    EMIT_STAMP(4);
 }
 
 /* One segment, glz_encode_tmpl.c:268-491.  All 256 lanes call this.
@@ -1581,6 +1608,7 @@ __device__ __forceinline__ void glz_parse_seg(const GlzDevJob &job, uint32_t seg
     long long a_tile = 0, a_scan = 0, a_res = 0, a_emit = 0, a_win = 0;
     if (tid == 0) {
         sh.st_fast = sh.st_gen = sh.st_ngen = 0;
+        for (int i = 0; i < 8; i++) sh.st_scan[i] = sh.st_emit[i] = 0;
     }
 #endif
     while (ip < ip_limit) {
@@ -1627,6 +1655,8 @@ __device__ __forceinline__ void glz_parse_seg(const GlzDevJob &job, uint32_t seg
         atomicAdd(&glz_stamp_acc[5], (unsigned long long)sh.st_fast);
         atomicAdd(&glz_stamp_acc[6], (unsigned long long)sh.st_gen);
         atomicAdd(&glz_stamp_acc[7], (unsigned long long)sh.st_ngen);
+        for (int i = 0; i < 6; i++) atomicAdd(&glz_stamp_acc[8 + i], (unsigned long long)sh.st_scan[i]);
+        for (int i = 0; i < 5; i++) atomicAdd(&glz_stamp_acc[14 + i], (unsigned long long)sh.st_emit[i]);
     }
 #endif
 

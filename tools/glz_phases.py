@@ -24,7 +24,7 @@ cap = 2 << 20
 outs = [gpu.malloc(cap) for _ in range(S)]
 plan = B.GlzBatchPlan(gpu, [dict(encoder=encs[s], type=8, width=W, height=H, stride=W * 4, chunks=[dev[s % pool][0]],
                                   chunk_rows=[H], out=outs[s], out_capacity=cap) for s in range(S)])
-st = (ctypes.c_ulonglong * 16)()
+st = (ctypes.c_ulonglong * 24)()
 names = ["tile", "scan", "resolve", "emit"]
 for k in range(F):
     lib.spice_gpu_debug_stamps(st, 1)
@@ -38,3 +38,7 @@ for k in range(F):
     print("frame %d: %.1f ms, %d windows (%.0f per session), cycles per window: %s | total %.0f | in resolve: fast loop %.0f, general %.0f (%.2f calls per window, %.0f cycles per call) | out %.0f KB per session"
           % (k, dt * 1e3, win, win / S, ", ".join("%s %.0f" % (n, a[i] / win) for i, n in enumerate(names)), tot / win,
              a[5] / win, a[6] / win, a[7] / win, a[6] / max(1, a[7]), sizes.mean() / 1e3), flush=True)
+    print("         inside scan: hash+bitmap+probe issue+barrier %.0f, nearest same-hash search %.0f, table entry check + pixel requests %.0f, window compares %.0f, table compare (waits for the pixels) %.0f, run length + results %.0f"
+          % tuple(a[8 + i] / win for i in range(6)), flush=True)
+    print("         inside emit: table stores %.0f, run bookkeeping %.0f, token sizes %.0f, prefix sum + barrier %.0f, writes %.0f"
+          % tuple(a[14 + i] / win for i in range(5)), flush=True)
