@@ -508,7 +508,8 @@ struct GlzShared {
     uint64_t neq[4];                   /* ... pixel differs from its predecessor */
     uint64_t slow[4];                  /* ... stops whose outcome wavefront 0 left in tok[] */
     uint32_t wave_sum[4];
-    uint32_t tail_h[2];                /* hashes stored beyond the window's end by its last match */
+    uint32_t tile_m2;                  /* raw pixel of position ip-2 */
+    uint32_t pend;                     /* table stores the last match left for positions ip-2 (bit 0) and ip-1 (bit 1) */
     int next_ip;
     /* output cursor.  Literal runs are written lazily: a count byte goes out
      * together with the first literal of every 32 (glz_encoder.c:89-108 writes
@@ -726,7 +727,8 @@ __device__ __forceinline__ void glz_run_from_arena(const GlzDevJob &job, const G
 template <int MODE>
 __device__ __forceinline__ void glz_window_scan(const GlzDevJob &job, const GlzDevSeg &cs,
                                                 uint32_t seg_idx, const GLZ_GLOBAL uint8_t *base, int ip,
-                                                int npix, int tid, uint32_t &my_h, bool &my_hv)
+                                                int npix, int tid, uint32_t pend, uint32_t th0, uint32_t th1,
+                                                uint32_t &my_h, bool &my_hv)
 {
     typedef GlzTraits<MODE> T;
     GlzShared &sh = glz_sh;
@@ -811,6 +813,13 @@ __device__ __forceinline__ void glz_window_scan(const GlzDevJob &job, const GlzD
         r[k] = 0;
     }
     if (look) {
+        /* the stores the previous window's last match left for positions ip-2 and
+         * ip-1 are the newest entries of their slots, whatever the probe saw */
+        if ((pend & 2u) && h == th1) {
+            he = make_uint2(seg_idx, (uint32_t)(ip - 1));
+        } else if ((pend & 1u) && h == th0) {
+            he = make_uint2(seg_idx, (uint32_t)(ip - 2));
+        }
         const GlzDevSeg rs = glz_seg(job, sh, he.x);
         const bool valid =
             he.x == seg_idx ||
@@ -1356,25 +1365,12 @@ __device__ __forceinline__ void glz_window_resolve(const GlzDevJob &job, uint32_
         }
     }
 
-    /* stores beyond the window: in the order the reference makes them,
-     * glz_encode_tmpl.c:424-444 */
-    uint32_t th0 = GLZ_NO_HASH, th1 = GLZ_NO_HASH;
-    if (t0 >= GLZ_WIN) {
-        th0 = glz_hash_at<MODE>(base, ip + t0);
-    }
-    if (t1 >= GLZ_WIN) {
-        th1 = glz_hash_at<MODE>(base, ip + t1);
-    }
+    /* Stores beyond the window (glz_encode_tmpl.c:424-444) wait for the next
+     * window: its tile holds the pixels their hashes are made of, so they cost no
+     * memory round trip here (glz_parse_seg makes them). */
     if (lane == 0) {
         sh.next_ip = ip + i; /* i counts every pixel consumed, also past the window */
-        sh.tail_h[0] = th0;
-        sh.tail_h[1] = th1;
-        if (t0 >= GLZ_WIN) {
-            glz_htab_store(job, th0, seg_idx, (uint32_t)(ip + t0));
-        }
-        if (t1 >= GLZ_WIN) {
-            glz_htab_store(job, th1, seg_idx, (uint32_t)(ip + t1));
-        }
+        sh.pend = (t0 >= GLZ_WIN ? 1u : 0u) | (t1 >= GLZ_WIN ? 2u : 0u);
     }
 }
 
@@ -1405,7 +1401,9 @@ __device__ __forceinline__ void glz_window_emit(const GlzDevJob &job, uint32_t s
     {
         const uint32_t *ins32 = (const uint32_t *)sh.ins;
         if (my_hv && ((ins32[p >> 5] >> (p & 31)) & 1u)) {
-            bool dominated = my_h == sh.tail_h[0] || my_h == sh.tail_h[1];
+            /* the last match's stores beyond the window are made after these, in
+             * program order, so they win a shared slot by themselves */
+            bool dominated = false;
             const uint32_t *row = &sh.bitmap[(my_h & (GLZ_KEYS - 1)) * 8];
             for (int v = p >> 5; v < 8 && !dominated; v++) {
                 uint32_t bits = row[v] & ins32[v];
@@ -1603,6 +1601,10 @@ __device__ __forceinline__ void glz_parse_seg(const GlzDevJob &job, uint32_t seg
     const int npix = (int)cs.nunits;
     const int ip_limit = npix - 6;
     int ip = from;
+    if (tid == 0) {
+        sh.pend = 0;
+    }
+    __syncthreads();
 
 #ifdef GLZ_STAMPS
     long long a_tile = 0, a_scan = 0, a_res = 0, a_emit = 0, a_win = 0;
@@ -1619,13 +1621,36 @@ __device__ __forceinline__ void glz_parse_seg(const GlzDevJob &job, uint32_t seg
             const int pos = ip - 1 + t;
             sh.tile[t] = (pos >= 0 && pos < npix) ? glz_load_px<MODE>(base, pos) : 0u;
         }
+        if (tid == GLZ_THREADS - 1) {
+            sh.tile_m2 = ip >= 2 ? glz_load_px<MODE>(base, ip - 2) : 0u;
+        }
         __syncthreads();
 #ifdef GLZ_STAMPS
         const long long t1 = STAMP();
 #endif
+        /* the table stores the previous window's last match left behind, now that
+         * the pixels are here: position ip-2 first, then ip-1, as the reference
+         * orders them */
+        const uint32_t pend = glz_uniform(sh.pend);
+        uint32_t th0 = GLZ_NO_HASH, th1 = GLZ_NO_HASH;
+        if (pend) {
+            typedef GlzTraits<MODE> T;
+            const uint32_t a = sh.tile_m2 & T::MASK, b = sh.tile[0] & T::MASK;
+            const uint32_t c = sh.tile[1] & T::MASK, d = sh.tile[2] & T::MASK;
+            th0 = glz_hash3<MODE>(a, b, c);
+            th1 = glz_hash3<MODE>(b, c, d);
+            if (tid == 0) {
+                if (pend & 1u) {
+                    glz_htab_store(job, th0, seg_idx, (uint32_t)(ip - 2));
+                }
+                if (pend & 2u) {
+                    glz_htab_store(job, th1, seg_idx, (uint32_t)(ip - 1));
+                }
+            }
+        }
         uint32_t my_h;
         bool my_hv;
-        glz_window_scan<MODE>(job, cs, seg_idx, base, ip, npix, tid, my_h, my_hv);
+        glz_window_scan<MODE>(job, cs, seg_idx, base, ip, npix, tid, pend, th0, th1, my_h, my_hv);
         __syncthreads();
 #ifdef GLZ_STAMPS
         const long long t2 = STAMP();
@@ -1662,6 +1687,23 @@ __device__ __forceinline__ void glz_parse_seg(const GlzDevJob &job, uint32_t seg
 
     /* ---- leftovers as literals, then the run closes; glz_encode_tmpl.c:466-487 */
     if (w0) {
+        /* stores the last window's last match left behind: no tile follows */
+        const uint32_t pend = glz_uniform(sh.pend);
+        if (pend & 1u) {
+            const uint32_t th0 = glz_hash_at<MODE>(base, ip - 2);
+            if (lane == 0) {
+                glz_htab_store(job, th0, seg_idx, (uint32_t)(ip - 2));
+            }
+        }
+        if (pend & 2u) {
+            const uint32_t th1 = glz_hash_at<MODE>(base, ip - 1);
+            if (lane == 0) {
+                glz_htab_store(job, th1, seg_idx, (uint32_t)(ip - 1));
+            }
+        }
+        if (lane == 0) {
+            sh.pend = 0;
+        }
         glz_run_from_arena<MODE>(job, base, ip, npix - ip, true, lane);
     }
     __syncthreads();
