@@ -32,6 +32,13 @@ for (w, h) in [(1, 1), (8, 8), (16, 16), (17, 9), (33, 17), (64, 48), (250, 130)
 CASES.append((3840, 2160, "smooth", 70, 1))
 CASES.append((3840, 2160, "smooth", 85, 0))
 CASES.append((1920, 1080, "desktop", 85, 0))
+# 4K frames that take the long Huffman paths (text edges, noise), and the stream encoder's
+# quality 80
+CASES.append((3840, 2160, "desktop", 80, 1))
+CASES.append((3840, 2160, "noise", 80, 1))
+CASES.append((3840, 2160, "desktop", 85, 0))
+CASES.append((3840, 2160, "noise", 70, 1))
+CASES.append((3840, 2160, "smooth", 80, 1))
 
 
 def pixels(fmt, bgrx):
