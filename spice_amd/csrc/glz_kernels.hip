@@ -527,6 +527,13 @@ struct GlzShared {
 __shared__ GlzShared glz_sh;
 #ifdef GLZ_STAMPS
 __device__ unsigned long long glz_stamp_acc[24];
+/* when each workgroup of the last launch started and ended (100 MHz clock) */
+__device__ unsigned long long glz_wg_times[8192 * 2];
+extern "C" void spice_gpu_debug_wg_times(unsigned long long *out, int n)
+{
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(glz_wg_times), sizeof(unsigned long long) * 2 * (size_t)n);
+}
 extern "C" void spice_gpu_debug_stamps(unsigned long long *out, int reset)
 {
     hipDeviceSynchronize();
@@ -1767,6 +1774,11 @@ glz_parse_kernel(const GlzDevJob *__restrict__ jobs, const uint32_t *__restrict_
     }
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
+#ifdef GLZ_STAMPS
+    if (tid == 0 && blockIdx.x < 8192) {
+        glz_wg_times[blockIdx.x * 2] = wall_clock64();
+    }
+#endif
 
     for (uint32_t u = (uint32_t)tid; u < job.nupd; u += GLZ_THREADS) {
         const GlzDevSegUpdate up = upd_pool[job.upd_off + u];
@@ -1828,6 +1840,11 @@ glz_parse_kernel(const GlzDevJob *__restrict__ jobs, const uint32_t *__restrict_
     if (tid == 0) {
         const uint32_t op = sh.op;
         *job.result = op > job.out_cap ? GLZ_DEV_ERR_NO_SPACE : (int32_t)op;
+#ifdef GLZ_STAMPS
+        if (blockIdx.x < 8192) {
+            glz_wg_times[blockIdx.x * 2 + 1] = wall_clock64();
+        }
+#endif
     }
 }
 
