@@ -1774,10 +1774,6 @@ glz_parse_kernel(const GlzDevJob *__restrict__ jobs, const uint32_t *__restrict_
     }
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
-    /* The host starts a batch's workgroups most expensive first, and the launch
-     * ends when its slowest image does: the instruction arbiter serves the first
-     * quarter of the grid before the second, and so on, so that the images the
-     * launch waits for are the ones that lose least to their neighbours on the CU. */
 #ifdef GLZ_STAMPS
     if (tid == 0 && blockIdx.x < 8192) {
         glz_wg_times[blockIdx.x * 2] = wall_clock64();
