@@ -254,6 +254,10 @@ class GlzWorkload:
                                        "runs_beside_parse": True}
         return r
 
+    def step_compulsory_bytes(self, out_bytes_per_step):
+        """4 B/px read + 4 B/px written into the HBM window + the streams; table traffic not counted"""
+        return self.S * self.W * self.H * 8 + out_bytes_per_step
+
     def after_timed(self):
         """Outside the timed region: one more step whose streams are compared with the CPU
         oracle's for sessions of --verify distinct sequences (a stream depends on the whole
@@ -815,6 +819,13 @@ def measure(cls, gpu, dist, args, geo, steps, warmup, e2e=True, cpu=True, **kw):
                                "orig_MB": round(sum(g[1] for g in gathered) / 1e6, 1),
                                "enc_MB": round(sum(g[2] for g in gathered) / 1e6, 1)}
         part["roofline"] = wl.roofline(times, steps, out_bytes)
+        if part["roofline"] and hasattr(wl, "step_compulsory_bytes"):
+            # every kernel of the step against the whole step's time: what the path must move
+            # (pixels in, pixels into the window, streams out) over the step's wall time
+            b = wl.step_compulsory_bytes(out_bytes / max(1, steps))
+            ach = b / (dt / steps) / 1e9
+            part["roofline"]["whole_step"] = {"compulsory_bytes_per_step": int(b), "achieved": round(ach, 2),
+                                              "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5)}
         part["kernel_ms"] = {k: round(v[1] / max(1, v[0]), 3) for k, v in times.items() if v[0]}
         part.update(extra)
         if e2e and not args.no_end_to_end and not args.sim and hasattr(wl, "end_to_end"):
