@@ -323,7 +323,9 @@ size_t spice_gpu_glz_out_bound(LzImageType type, int width, int height);
  * caller's job order -- the batch is cut into as many launches as the most
  * images any one dictionary gets -- and produce exactly the streams that
  * separate glz_encode calls in that order would.  Submit and finish must be
- * called by the same thread, or by two threads that hand the batch over.  An image of one chunk is parsed where
+ * called by the same thread (the batch holds its dictionaries' locks between the
+ * two; a finish from another thread is refused and the batch stays in flight).
+ * An image of one chunk is parsed where
  * the caller put it and its copy runs beside the parse; other images are copied
  * first.  The chunk buffers must stay valid and unchanged until the call (or
  * spice_gpu_glz_finish) returns.  Workgroups start in the order of expected

@@ -682,6 +682,21 @@ def glz_encode_batch(gpu, items, split=False, raise_on_error=True):
     the order given.  Returns (sizes, window images); with raise_on_error=False a
     failed batch returns too, the failed jobs with a size <= 0."""
     n = len(items)
+    jobs, keep = glz_jobs(items)
+    if split:
+        rc = gpu.L.spice_gpu_glz_submit(jobs, n)
+        if rc == 0:
+            rc = gpu.L.spice_gpu_glz_finish(jobs, n)
+    else:
+        rc = gpu.L.spice_gpu_glz_encode_batch(jobs, n)
+    if rc != 0 and raise_on_error:
+        raise SpiceGpuError("glz batch: " + gpu.last_error())
+    return [jobs[j].out_size for j in range(n)], [jobs[j].dict_image for j in range(n)]
+
+
+def glz_jobs(items):
+    """The SpiceGpuGlzJob array of a batch (and what must stay alive beside it)."""
+    n = len(items)
     jobs = (SpiceGpuGlzJob * n)()
     keep = []
     for j, it in enumerate(items):
@@ -698,15 +713,7 @@ def glz_encode_batch(gpu, items, split=False, raise_on_error=True):
         jobs[j].chunk_rows = rows
         jobs[j].out, jobs[j].out_capacity = it["out"], it["out_capacity"]
         jobs[j].usr_context = it.get("usr_context", 0)
-    if split:
-        rc = gpu.L.spice_gpu_glz_submit(jobs, n)
-        if rc == 0:
-            rc = gpu.L.spice_gpu_glz_finish(jobs, n)
-    else:
-        rc = gpu.L.spice_gpu_glz_encode_batch(jobs, n)
-    if rc != 0 and raise_on_error:
-        raise SpiceGpuError("glz batch: " + gpu.last_error())
-    return [jobs[j].out_size for j in range(n)], [jobs[j].dict_image for j in range(n)]
+    return jobs, keep
 
 
 class GlzBatchPlan:

@@ -21,6 +21,7 @@
 #include <condition_variable>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "glz_device.h"
@@ -704,6 +705,7 @@ struct Flight {
     size_t nlevels = 0;
     int njobs = 0;
     std::vector<std::unique_lock<std::recursive_mutex>> dict_locks;
+    std::thread::id owner; /* the thread that submitted: its dictionary locks are its own */
     bool active = false;
     uint64_t t0 = 0;
     uint64_t host_ns = 0; /* host time of the last submit + finish, waiting excluded */
@@ -1416,6 +1418,7 @@ int spice_gpu_glz_submit(SpiceGpuGlzJob *jobs, int njobs)
         return -1;
     }
     f.dict_locks = std::move(dict_locks);
+    f.owner = std::this_thread::get_id();
     f.active = true;
     f.host_ns = now_ns() - t_in;
     return 0;
@@ -1426,6 +1429,12 @@ int spice_gpu_glz_finish(SpiceGpuGlzJob *jobs, int njobs)
     Flight &f = g_flight;
     if (!f.active || njobs != f.njobs) {
         set_error("glz batch: finish without a matching submit");
+        return -1;
+    }
+    if (f.owner != std::this_thread::get_id()) {
+        /* the batch holds its dictionaries' locks, and a lock is released by the
+         * thread that took it; the batch stays in flight for its own thread */
+        set_error("glz batch: finish must be called by the thread that submitted the batch");
         return -1;
     }
     bool ok = check(hipStreamSynchronize(stream()), "glz batch sync");

@@ -222,6 +222,40 @@ def test_sim_failed_batches_leave_windows_usable(sim, oracle):
             s.close()
 
 
+def run_finish_thread_rule(dev, oracle):
+    """a batch in flight holds its dictionaries' locks: only the submitting thread may
+    finish it; another thread is refused and the batch stays in flight"""
+    import threading
+    sessions = [Session(dev, oracle, B.LZ_IMAGE_TYPE_RGB32, 96, 40, "desktop", seed=31 + k, window=1 << 14)
+                for k in range(2)]
+    try:
+        for f in range(2):
+            items = [s.next_image() for s in sessions]
+            jobs, keep = B.glz_jobs(items)
+            assert dev.L.spice_gpu_glz_submit(jobs, len(items)) == 0, dev.last_error()
+            got = {}
+
+            def other():
+                got["rc"] = dev.L.spice_gpu_glz_finish(jobs, len(items))
+                got["err"] = dev.last_error()
+
+            t = threading.Thread(target=other)
+            t.start()
+            t.join()
+            assert got["rc"] == -1 and "thread" in got["err"], got
+            assert dev.L.spice_gpu_glz_finish(jobs, len(items)) == 0, dev.last_error()
+            for s, j in zip(sessions, range(len(items))):
+                s.check(jobs[j].out_size, "frame %d, finished by its own thread" % f)
+            del keep
+    finally:
+        for s in sessions:
+            s.close()
+
+
+def test_sim_finish_thread_rule(sim, oracle):
+    run_finish_thread_rule(sim, oracle)
+
+
 def run_plan(dev, oracle, n, w, h, nframes, window):
     """GlzBatchPlan: the job array is built once and only the frame pointers change"""
     seqs = [frames.DesktopSequence(max(w, 96), max(h, 96), seed=70 + k) for k in range(n)]
@@ -266,6 +300,11 @@ def test_gpu_batch_of_mixed_sessions(gpu, oracle):
     big = SMALL + [(B.LZ_IMAGE_TYPE_RGB32, 640, 400, "desktop"), (B.LZ_IMAGE_TYPE_RGB32, 320, 200, "noise"),
                    (B.LZ_IMAGE_TYPE_RGBA, 300, 300, "desktop"), (B.LZ_IMAGE_TYPE_RGB32, 1024, 64, "flat")]
     run_batches(gpu, oracle, big, 6, window=1 << 19)
+
+
+@pytest.mark.gpu
+def test_gpu_finish_thread_rule(gpu, oracle):
+    run_finish_thread_rule(gpu, oracle)
 
 
 @pytest.mark.gpu
