@@ -1223,8 +1223,14 @@ void jpeg_launch(const JpegDevJob *jobs, int njobs, int max_groups, bool any_isl
      * between two launches costs about as much as the offsets kernel itself */
     t = timed ? spicegpu::timing_begin("jpeg_bitstream_kernels", stream) : -1;
     hipLaunchKernelGGL(jpeg_offsets_kernel, dim3((unsigned)njobs), dim3(JT), 0, stream, jobs);
-    hipLaunchKernelGGL(jpeg_gather_kernel, dim3(64, (unsigned)njobs), dim3(JT), 0, stream, jobs);
-    hipLaunchKernelGGL(jpeg_finish_kernel, dim3(64, (unsigned)njobs), dim3(JT), 0, stream, jobs);
+    /* a workgroup takes the scan 4 KiB at a time; a group of strips (10 240 pixels)
+     * leaves about that much at video qualities, so the largest job gets a workgroup
+     * per few chunks and the passes are not a chain of dependent round trips (16 4K
+     * frames: 0.048 -> 0.041 ms for the three kernels with 256 instead of 64) */
+    unsigned per_job = (unsigned)max_groups / 3u;
+    per_job = per_job < 16u ? 16u : (per_job > 256u ? 256u : per_job);
+    hipLaunchKernelGGL(jpeg_gather_kernel, dim3(per_job, (unsigned)njobs), dim3(JT), 0, stream, jobs);
+    hipLaunchKernelGGL(jpeg_finish_kernel, dim3(per_job, (unsigned)njobs), dim3(JT), 0, stream, jobs);
     spicegpu::timing_end(t, stream);
 }
 
