@@ -77,9 +77,14 @@
 #ifdef SPICE_WAVE_SIM
 #define GLZ_GLOBAL
 #define GLZ_SEVEN_PER_CU
+#define GLZ_RECOMPUTE(v)
 #else
 #define GLZ_GLOBAL __attribute__((address_space(1)))
 #define GLZ_SEVEN_PER_CU __attribute__((amdgpu_waves_per_eu(7, 7))) /* 72 VGPRs */
+/* Hides where a lane index came from: what is derived from it is worked out again in
+ * every window (an instruction or two) instead of being hoisted out of the window loop
+ * into registers that the 72-register budget then spills to scratch memory. */
+#define GLZ_RECOMPUTE(v) asm volatile("" : "+v"(v))
 #endif
 typedef uint32_t glz_u32x4 __attribute__((vector_size(16)));
 typedef glz_u32x4 glz_u32x4_u __attribute__((aligned(4))); /* pixel-aligned only */
@@ -623,6 +628,21 @@ __device__ __forceinline__ GlzDevSeg glz_seg(const GlzDevJob &job, const GlzShar
     return glz_load_seg(job, idx);
 }
 
+/* A segment record every lane asked for with the same index: held in scalar
+ * registers from here on (as vector registers its eight dwords, live across the
+ * whole window loop, are the first thing the register allocator spills) */
+__device__ __forceinline__ GlzDevSeg glz_seg_uniform(const GlzDevSeg &v)
+{
+    GlzDevSeg s;
+    s.pixels_so_far = glz_uniform64(v.pixels_so_far);
+    s.image_id = glz_uniform64(v.image_id);
+    s.arena_off16 = glz_uniform(v.arena_off16);
+    s.nunits = glz_uniform(v.nunits);
+    s.img_first_delta = glz_uniform(v.img_first_delta);
+    s.flags = glz_uniform(v.flags);
+    return s;
+}
+
 __device__ __forceinline__ uint32_t glz_pick4(uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, int w)
 {
     return w == 0 ? r0 : (w == 1 ? r1 : (w == 2 ? r2 : r3));
@@ -743,6 +763,7 @@ __device__ __forceinline__ void glz_window_scan(const GlzDevJob &job, const GlzD
     long long ss_ = STAMP();
 #endif
     const int ip_bound = npix - 2, ip_limit = npix - 6;
+    GLZ_RECOMPUTE(tid);
     const int p = tid, q = ip + p;
     const bool act = q < ip_limit;
     const bool hv = q + 2 < npix;
@@ -1392,6 +1413,7 @@ __device__ __forceinline__ void glz_window_emit(const GlzDevJob &job, uint32_t s
 #ifdef GLZ_STAMPS
     long long es_ = STAMP();
 #endif
+    GLZ_RECOMPUTE(tid);
     const int lane = tid & 63, p = tid;
     const int w = (int)glz_uniform((uint32_t)(tid >> 6));
     const uint64_t lit0 = glz_uniform64(sh.lit[0]), lit1 = glz_uniform64(sh.lit[1]);
@@ -1603,7 +1625,7 @@ __device__ __forceinline__ void glz_parse_seg(const GlzDevJob &job, uint32_t seg
     GlzShared &sh = glz_sh;
     const int lane = tid & 63;
     const bool w0 = tid < GLZ_WAVE;
-    const GlzDevSeg cs = glz_seg(job, sh, seg_idx);
+    const GlzDevSeg cs = glz_seg_uniform(glz_seg(job, sh, seg_idx));
     const GLZ_GLOBAL uint8_t *base = glz_seg_base(job, seg_idx, cs);
     const int npix = (int)cs.nunits;
     const int ip_limit = npix - 6;

@@ -10,7 +10,8 @@ from spice_amd import binding as B, frames
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 F = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 POOL = int(sys.argv[3]) if len(sys.argv) > 3 else 64
-lib = ctypes.CDLL(os.path.join(ROOT, "tools", "diag", "libspicegpu_stamps.so"))
+# GLZ_STAMPS_LIB names another stamped build under tools/diag/ (two builds compared on one box)
+lib = ctypes.CDLL(os.path.join(ROOT, "tools", "diag", os.environ.get("GLZ_STAMPS_LIB", "libspicegpu_stamps.so")))
 gpu = B.SpiceGpu(lib); gpu.init(0)
 W, H = 1920, 1080
 pool = min(POOL, S)
