@@ -42,7 +42,11 @@
 #define GLZ_WIN 256                       /* window positions per step */
 #define GLZ_K 8                           /* pixels every lane pre-compares against a candidate; above every type's MAX_REF */
 #define GLZ_TILE (GLZ_WIN + GLZ_K + 4)    /* LDS pixels: positions ip-1 .. ip+WIN+K+2 */
-#define GLZ_SEG_CACHE 64                  /* segment slots mirrored in LDS */
+#ifdef GLZ_STAMPS
+#define GLZ_SEG_CACHE 48                  /* the diagnostic build's counters take the place of eight slots */
+#else
+#define GLZ_SEG_CACHE 56                  /* segment slots mirrored in LDS (what 20 KB per workgroup leave) */
+#endif
 #define GLZ_KEYS 256                      /* rows of the same-hash bitmap */
 #define GLZ_NO_HASH 0xffffffffu
 
@@ -76,14 +80,14 @@
  * global loads and values read at a wave-uniform address stay wave-uniform. */
 #ifdef SPICE_WAVE_SIM
 #define GLZ_GLOBAL
-#define GLZ_SEVEN_PER_CU
+#define GLZ_EIGHT_PER_CU
 #define GLZ_RECOMPUTE(v)
 #else
 #define GLZ_GLOBAL __attribute__((address_space(1)))
-#define GLZ_SEVEN_PER_CU __attribute__((amdgpu_waves_per_eu(7, 7))) /* 72 VGPRs */
+#define GLZ_EIGHT_PER_CU __attribute__((amdgpu_waves_per_eu(8, 8))) /* 64 VGPRs */
 /* Hides where a lane index came from: what is derived from it is worked out again in
  * every window (an instruction or two) instead of being hoisted out of the window loop
- * into registers that the 72-register budget then spills to scratch memory. */
+ * into registers that the 64-register budget then spills to scratch memory. */
 #define GLZ_RECOMPUTE(v) asm volatile("" : "+v"(v))
 #endif
 typedef uint32_t glz_u32x4 __attribute__((vector_size(16)));
@@ -507,7 +511,6 @@ struct GlzShared {
     uint32_t g_seg[GLZ_WIN];
     uint32_t tok[GLZ_WIN];             /* per match start: length | GLZ_SEL_* << 29 */
     uint32_t tok_pdist[GLZ_WIN];       /* pixel distance of a GLZ_SEL_DEEP match */
-    uint32_t qword[GLZ_WIN];           /* GLZ_W_*: what wavefront 0 walked on */
     GlzDevSeg seg_cache[GLZ_SEG_CACHE];
     uint64_t lit[4], ms[4], ins[4];    /* window positions: literal stops, match starts, table stores */
     uint64_t neq[4];                   /* ... pixel differs from its predecessor */
@@ -529,6 +532,7 @@ struct GlzShared {
 #endif
 };
 
+static_assert(sizeof(GlzShared) <= 20 * 1024, "eight workgroups per CU share 160 KB of LDS");
 __shared__ GlzShared glz_sh;
 #ifdef GLZ_STAMPS
 __device__ unsigned long long glz_stamp_acc[24];
@@ -1316,7 +1320,6 @@ __device__ __forceinline__ void glz_window_resolve(const GlzDevJob &job, uint32_
         uint64_t ins = glz_tail_bits(t0, t1, Q), stops = 0, ms = 0, slow = 0;
         __builtin_amdgcn_wave_barrier(); /* lane 0's marks of the finished quarters are read below */
         const uint32_t W = glz_quarter_words<MODE>(Q, lane);
-        sh.qword[Q * 64 + lane] = W;
         int l = i & 63;
         int last_len = 0;
 
@@ -1532,7 +1535,7 @@ __device__ __forceinline__ void glz_window_emit(const GlzDevJob &job, uint32_t s
         if ((sh.slow[p >> 6] >> lane) & 1) {
             tok = sh.tok[p];
         } else if (a & GLZ_A_RLE) {
-            tok = (sh.qword[p] & 0x1ffu) | (GLZ_SEL_RUN << 29);
+            tok = (b & 0x1ffu) | (GLZ_SEL_RUN << 29); /* the run's length, as the scan left it */
         } else if ((a & GLZ_A_P1V) && ((ins32[n1 >> 5] >> (n1 & 31u)) & 1u)) {
             /* the same choice wavefront 0 made, now that every store is known */
             tok = ((a >> GLZ_A_LEN1_SHIFT) & 31u) | (GLZ_SEL_P1 << 29);
@@ -1782,10 +1785,10 @@ __device__ __forceinline__ void glz_parse_image(const GlzDevJob &job, const uint
 /* One workgroup per job: apply the window-table updates, write the header
  * (glz_encoder.c:264-276), parse, report the size. */
 template <int TYPE>
-/* Seven workgroups per CU (72 VGPRs with some dwords spilled, 21 KB of LDS each):
- * a session's parse is bound by its own latency chain, so the GPU's throughput
- * is the number of sessions it holds at once. */
-__global__ void __launch_bounds__(GLZ_THREADS) GLZ_SEVEN_PER_CU
+/* Eight workgroups per CU, all a CU's 32 wave slots (64 VGPRs, 20 KB of LDS
+ * each -- GlzShared is sized for it): a session's parse is bound by its own latency
+ * chain, so the GPU's throughput is the number of sessions it holds at once. */
+__global__ void __launch_bounds__(GLZ_THREADS) GLZ_EIGHT_PER_CU
 glz_parse_kernel(const GlzDevJob *__restrict__ jobs, const uint32_t *__restrict__ u32_pool,
                  const GlzDevSegUpdate *__restrict__ upd_pool)
 {

@@ -12,7 +12,7 @@ from spice_amd import binding as B, frames
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 3072
 F = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 POOL = int(sys.argv[3]) if len(sys.argv) > 3 else 256
-SLOTS = 1792
+SLOTS = 2048
 lib = ctypes.CDLL(os.path.join(ROOT, "tools", "diag", "libspicegpu_stamps.so"))
 gpu = B.SpiceGpu(lib); gpu.init(0)
 W, H = 1920, 1080
