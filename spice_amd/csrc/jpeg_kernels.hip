@@ -538,16 +538,20 @@ __device__ __forceinline__ void jpeg_strip_body(const JpegDevJob &job, const uin
     __shared__ uint32_t rings[(JT / 64) * JRING_WORDS];
 
     const int tid = (int)threadIdx.x;
+    /* Where the group lies is the same for every lane, but the divisions are done
+     * in vector registers: moved to scalar ones here, or the pixel loaders, which
+     * use them for every item, fetch them back from scratch memory each time. */
     const int groups_per_row = (job.strips_per_row + JPEG_GROUP_STRIPS - 1) / JPEG_GROUP_STRIPS;
-    const int my = group / groups_per_row;
-    const int first_strip = (group % groups_per_row) * JPEG_GROUP_STRIPS;
+    const int my = __builtin_amdgcn_readfirstlane(group / groups_per_row);
+    const int first_strip = __builtin_amdgcn_readfirstlane((group % groups_per_row) * JPEG_GROUP_STRIPS);
     const int mx0 = first_strip * JPEG_STRIP_MCUS;
     const int nm = min(JG_MCUS, job.mcu_cols - mx0);
     const bool has_halo = group != 0;
     const int ns = nm + 1;
     /* the MCU coded just before this strip */
     const int hlin = my * job.mcu_cols + mx0 - 1;
-    const int hy = has_halo ? hlin / job.mcu_cols : 0, hx = has_halo ? hlin % job.mcu_cols : 0;
+    const int hy = __builtin_amdgcn_readfirstlane(has_halo ? hlin / job.mcu_cols : 0);
+    const int hx = __builtin_amdgcn_readfirstlane(has_halo ? hlin % job.mcu_cols : 0);
 
     for (int i = tid; i < JHUFF_WORDS; i += JT) {
         huff[i] = huff_g[i];
