@@ -435,6 +435,7 @@ __device__ __forceinline__ void jpeg_load_tiles_wide(const JpegDevJob &job, uint
         return;
     }
     const int cols = ns * 4; /* four-pixel columns of a tile row */
+    const int64_t main_row = (int64_t)(my * 16) * job.stride, halo_row = (int64_t)(hy * 16) * job.stride;
     const float inv = 1.0f / (float)cols;
     constexpr int ITERS = (JSLOTS * 4 * 8 + JT - 1) / JT;
     uint32_t px[ITERS][2 * NW];
@@ -449,14 +450,17 @@ __device__ __forceinline__ void jpeg_load_tiles_wide(const JpegDevJob &job, uint
         if (item < cols * 8) {
             /* item / cols; exact: the quotient is below 8 and cols below 2^8 */
             const int qy = (int)(((float)item + 0.5f) * inv);
-            const int cx = item - qy * cols;
+            const int cx = item - __mul24(qy, cols);
             const int slot = cx >> 2;
             const int mcx = slot == 0 ? hx : mx0 + slot - 1;
             const int mcy = slot == 0 ? hy : my;
             const int x = mcx * 16 + (cx & 3) * 4, y = mcy * 16 + qy * 2;
             if ((slot != 0 || has_halo) && x + 3 < W && y + 1 < H) {
-                const JPEG_GLOBAL uint8_t *row =
-                    (const JPEG_GLOBAL uint8_t *)(uintptr_t)job.pixels + (int64_t)y * job.stride + x * PXB;
+                /* the MCU row's first line is the same for every lane (scalar 64-bit
+                 * product); the line inside it and the column fit 24-bit multiplies */
+                const JPEG_GLOBAL uint8_t *row = (const JPEG_GLOBAL uint8_t *)(uintptr_t)job.pixels +
+                                                 (slot == 0 ? halo_row : main_row) + __mul24(qy * 2, job.stride) +
+                                                 x * PXB;
                 const JPEG_GLOBAL uint32_t *a = (const JPEG_GLOBAL uint32_t *)row;
                 const JPEG_GLOBAL uint32_t *b = (const JPEG_GLOBAL uint32_t *)(row + job.stride);
 #pragma unroll
@@ -475,7 +479,7 @@ __device__ __forceinline__ void jpeg_load_tiles_wide(const JpegDevJob &job, uint
             continue;
         }
         const int qy = (int)(((float)item + 0.5f) * inv);
-        const int cx = item - qy * cols;
+        const int cx = item - __mul24(qy, cols);
         const int slot = cx >> 2;
         if (slot == 0 && !has_halo) {
             continue;
@@ -489,7 +493,7 @@ __device__ __forceinline__ void jpeg_load_tiles_wide(const JpegDevJob &job, uint
             for (int k = 0; k < 8; k++) {
                 jpeg_ycc<FMT>(raw[k], yy[k], cb[k], cr[k]);
             }
-            uint8_t *yp = &ytile[(qy * 2) * YT_STRIDE + slot * 16 + (cx & 3) * 4];
+            uint8_t *yp = &ytile[__mul24(qy * 2, YT_STRIDE) + slot * 16 + (cx & 3) * 4];
             *(uint32_t *)yp = (uint32_t)yy[0] | ((uint32_t)yy[1] << 8) | ((uint32_t)yy[2] << 16) | ((uint32_t)yy[3] << 24);
             *(uint32_t *)(yp + YT_STRIDE) =
                 (uint32_t)yy[4] | ((uint32_t)yy[5] << 8) | ((uint32_t)yy[6] << 16) | ((uint32_t)yy[7] << 24);
@@ -498,7 +502,7 @@ __device__ __forceinline__ void jpeg_load_tiles_wide(const JpegDevJob &job, uint
             const uint32_t cb1 = (uint32_t)(cb[2] + cb[3] + cb[6] + cb[7] + 2) >> 2;
             const uint32_t cr0 = (uint32_t)(cr[0] + cr[1] + cr[4] + cr[5] + 1) >> 2;
             const uint32_t cr1 = (uint32_t)(cr[2] + cr[3] + cr[6] + cr[7] + 2) >> 2;
-            const int co = qy * CT_STRIDE + slot * 8 + (cx & 3) * 2;
+            const int co = __mul24(qy, CT_STRIDE) + slot * 8 + (cx & 3) * 2;
             *(uint16_t *)&cbtile[co] = (uint16_t)(cb0 | (cb1 << 8));
             *(uint16_t *)&crtile[co] = (uint16_t)(cr0 | (cr1 << 8));
         } else {
