@@ -381,6 +381,54 @@ __device__ __forceinline__ void jpeg_ycc_bgrx(uint32_t p, int &yy, int &cb, int 
     cr = ((r << 15) - 27439 * g - 5329 * b + ((128 << 16) + 32767)) >> 16;
 }
 
+/* Two pixels stored b,g,r in their low three bytes at once.  The same integers as
+ * jpeg_ycc_bgrx, computed in single precision: every product and partial sum is a
+ * multiple of 2^-16 below 2^8 (at most 2^24 - 1 in units of 2^-16: K + 32768 x 255 =
+ * 16 777 215), so nothing is rounded, and the conversion back truncates exactly where
+ * the shift by 16 does.  A byte becomes a float in one instruction, which pays for the
+ * byte extraction, and two pixels share every multiply-add (v_pk_fma_f32). */
+__device__ __forceinline__ void jpeg_ycc_pair(uint32_t p0, uint32_t p1, int &y0, int &y1, int &cb0,
+                                              int &cb1, int &cr0, int &cr1)
+{
+    const float s = 1.0f / 65536.0f, k = (float)((128 << 16) + 32767) * s;
+#ifdef SPICE_WAVE_SIM
+    const uint32_t px[2] = {p0, p1};
+    int o[2][3];
+    for (int i = 0; i < 2; i++) {
+        const float b = (float)(px[i] & 0xff), g = (float)((px[i] >> 8) & 0xff), r = (float)((px[i] >> 16) & 0xff);
+        o[i][0] = (int)(b * (7471.0f * s) + (g * (38470.0f * s) + (r * (19595.0f * s) + 32768.0f * s)));
+        o[i][1] = (int)(g * (-21709.0f * s) + (r * (-11059.0f * s) + (b * 0.5f + k)));
+        o[i][2] = (int)(b * (-5329.0f * s) + (g * (-27439.0f * s) + (r * 0.5f + k)));
+    }
+    y0 = o[0][0];
+    cb0 = o[0][1];
+    cr0 = o[0][2];
+    y1 = o[1][0];
+    cb1 = o[1][1];
+    cr1 = o[1][2];
+#else
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 b = {(float)(p0 & 0xff), (float)(p1 & 0xff)};
+    const f2 g = {(float)((p0 >> 8) & 0xff), (float)((p1 >> 8) & 0xff)};
+    const f2 r = {(float)((p0 >> 16) & 0xff), (float)((p1 >> 16) & 0xff)};
+    f2 y = __builtin_elementwise_fma(r, (f2)(19595.0f * s), (f2)(32768.0f * s));
+    y = __builtin_elementwise_fma(g, (f2)(38470.0f * s), y);
+    y = __builtin_elementwise_fma(b, (f2)(7471.0f * s), y);
+    f2 cb = __builtin_elementwise_fma(b, (f2)(0.5f), (f2)(k));
+    cb = __builtin_elementwise_fma(r, (f2)(-11059.0f * s), cb);
+    cb = __builtin_elementwise_fma(g, (f2)(-21709.0f * s), cb);
+    f2 cr = __builtin_elementwise_fma(r, (f2)(0.5f), (f2)(k));
+    cr = __builtin_elementwise_fma(g, (f2)(-27439.0f * s), cr);
+    cr = __builtin_elementwise_fma(b, (f2)(-5329.0f * s), cr);
+    y0 = (int)y.x;
+    y1 = (int)y.y;
+    cb0 = (int)cb.x;
+    cb1 = (int)cb.y;
+    cr0 = (int)cr.x;
+    cr1 = (int)cr.y;
+#endif
+}
+
 /* Four stored pixels from the words of a row piece (4, 3 or 2 words by format) */
 template <int FMT>
 __device__ __forceinline__ void jpeg_unpack4(const uint32_t *w, uint32_t *raw)
@@ -489,9 +537,16 @@ __device__ __forceinline__ void jpeg_load_tiles_wide(const JpegDevJob &job, uint
             jpeg_unpack4<FMT>(&px[it][0], &raw[0]);
             jpeg_unpack4<FMT>(&px[it][NW], &raw[4]);
             int yy[8], cb[8], cr[8];
+            if (FMT == 8 || FMT == 9 || FMT == 7) {
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                jpeg_ycc<FMT>(raw[k], yy[k], cb[k], cr[k]);
+                for (int k = 0; k < 8; k += 2) {
+                    jpeg_ycc_pair(raw[k], raw[k + 1], yy[k], yy[k + 1], cb[k], cb[k + 1], cr[k], cr[k + 1]);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    jpeg_ycc<FMT>(raw[k], yy[k], cb[k], cr[k]);
+                }
             }
             uint8_t *yp = &ytile[__mul24(qy * 2, YT_STRIDE) + slot * 16 + (cx & 3) * 4];
             *(uint32_t *)yp = (uint32_t)yy[0] | ((uint32_t)yy[1] << 8) | ((uint32_t)yy[2] << 16) | ((uint32_t)yy[3] << 24);

@@ -131,6 +131,19 @@ def test_gpu_golden_4k_and_1080p(gpu, oracle):
 
 
 @pytest.mark.gpu
+def test_gpu_every_colour(gpu, oracle):
+    """all 2^24 colours, each filling a 2x2 block (so that the chroma averages are the colour's
+    own Cb and Cr), at quality 100: the colour conversion has no input left untried"""
+    w = h = 4096
+    for part in range(4):
+        c = np.arange(part << 22, (part + 1) << 22, dtype=np.uint32).reshape(h // 2, w // 2)
+        px = np.repeat(np.repeat(c, 2, axis=0), 2, axis=1).view(np.uint8).reshape(h, w * 4)
+        want = oracle.jpeg_encode(px, w, h, w * 4, oracle.FMT_32BIT, 100, oracle.DCT_ISLOW)
+        got = batch_encode(gpu, [(px, w, h, B.BITMAP_FMT_32BIT, 100, 0, 1)])[0]
+        assert_same_stream(want, got, "colours %d..%d" % (part << 22, ((part + 1) << 22) - 1))
+
+
+@pytest.mark.gpu
 def test_gpu_mjpeg_api(gpu, oracle):
     run_mjpeg_api(gpu, oracle, [(640, 480, 8), (333, 177, 7), (1280, 720, 6), (17, 33, 9), (1920, 1080, 8)])
 
