@@ -484,31 +484,35 @@ __device__ __forceinline__ void jpeg_load_tiles_wide(const JpegDevJob &job, uint
     }
     const int cols = ns * 4; /* four-pixel columns of a tile row */
     const int64_t main_row = (int64_t)(my * 16) * job.stride, halo_row = (int64_t)(hy * 16) * job.stride;
-    const float inv = 1.0f / (float)cols;
-    constexpr int ITERS = (JSLOTS * 4 * 8 + JT - 1) / JT;
+    /* Items are (line pair qy of the MCU row, four-pixel column cx).  A lane keeps its
+     * line pair and walks the columns 32 apart, so that the line's address, the tile
+     * rows and the bounds in y are worked out once; only the columns from 160 on, at
+     * most 4 x 8 items, are dealt out again, to the first 32 lanes.  Column cx lies
+     * at x = 16 (mx0 - 1) + 4 cx, but for the halo's four (cx < 4), which belong to
+     * the MCU coded before this group, maybe on the MCU row above. */
+    constexpr int FULL = (JSLOTS * 4) / 32, ITERS = FULL + 1;
+    static_assert(JT == 256 && (JSLOTS * 4 - FULL * 32) * 8 <= 32, "tail items fit the first 32 lanes");
+    const int rq = tid >> 5, c0 = tid & 31;
+    const int xb = (mx0 - 1) * 16;
+    const JPEG_GLOBAL uint8_t *const pixels = (const JPEG_GLOBAL uint8_t *)(uintptr_t)job.pixels;
     uint32_t px[ITERS][2 * NW];
     unsigned fast = 0;
 #pragma unroll
     for (int it = 0; it < ITERS; it++) {
-        const int item = tid + it * JT;
+        const int qy = it < FULL ? rq : tid >> 2;
+        const int cx = it < FULL ? c0 + 32 * it : FULL * 32 + (tid & 3);
 #pragma unroll
         for (int k = 0; k < 2 * NW; k++) {
             px[it][k] = 0;
         }
-        if (item < cols * 8) {
-            /* item / cols; exact: the quotient is below 8 and cols below 2^8 */
-            const int qy = (int)(((float)item + 0.5f) * inv);
-            const int cx = item - __mul24(qy, cols);
-            const int slot = cx >> 2;
-            const int mcx = slot == 0 ? hx : mx0 + slot - 1;
-            const int mcy = slot == 0 ? hy : my;
-            const int x = mcx * 16 + (cx & 3) * 4, y = mcy * 16 + qy * 2;
-            if ((slot != 0 || has_halo) && x + 3 < W && y + 1 < H) {
+        if (cx < cols && (it < FULL || tid < 32)) {
+            const bool halo = it == 0 && cx < 4;
+            const int x = (halo ? hx * 16 : xb) + cx * 4, y = (halo ? hy : my) * 16 + qy * 2;
+            if ((!halo || has_halo) && x + 3 < W && y + 1 < H) {
                 /* the MCU row's first line is the same for every lane (scalar 64-bit
                  * product); the line inside it and the column fit 24-bit multiplies */
-                const JPEG_GLOBAL uint8_t *row = (const JPEG_GLOBAL uint8_t *)(uintptr_t)job.pixels +
-                                                 (slot == 0 ? halo_row : main_row) + __mul24(qy * 2, job.stride) +
-                                                 x * PXB;
+                const JPEG_GLOBAL uint8_t *row =
+                    pixels + (halo ? halo_row : main_row) + __mul24(qy * 2, job.stride) + x * PXB;
                 const JPEG_GLOBAL uint32_t *a = (const JPEG_GLOBAL uint32_t *)row;
                 const JPEG_GLOBAL uint32_t *b = (const JPEG_GLOBAL uint32_t *)(row + job.stride);
 #pragma unroll
@@ -522,14 +526,13 @@ __device__ __forceinline__ void jpeg_load_tiles_wide(const JpegDevJob &job, uint
     }
 #pragma unroll
     for (int it = 0; it < ITERS; it++) {
-        const int item = tid + it * JT;
-        if (item >= cols * 8) {
+        const int qy = it < FULL ? rq : tid >> 2;
+        const int cx = it < FULL ? c0 + 32 * it : FULL * 32 + (tid & 3);
+        if (cx >= cols || (it >= FULL && tid >= 32)) {
             continue;
         }
-        const int qy = (int)(((float)item + 0.5f) * inv);
-        const int cx = item - __mul24(qy, cols);
-        const int slot = cx >> 2;
-        if (slot == 0 && !has_halo) {
+        const bool halo = it == 0 && cx < 4;
+        if (halo && !has_halo) {
             continue;
         }
         if (fast & (1u << it)) {
@@ -548,7 +551,8 @@ __device__ __forceinline__ void jpeg_load_tiles_wide(const JpegDevJob &job, uint
                     jpeg_ycc<FMT>(raw[k], yy[k], cb[k], cr[k]);
                 }
             }
-            uint8_t *yp = &ytile[__mul24(qy * 2, YT_STRIDE) + slot * 16 + (cx & 3) * 4];
+            /* slot * 16 + (cx & 3) * 4 is cx * 4: a tile row is the columns side by side */
+            uint8_t *yp = &ytile[__mul24(qy * 2, YT_STRIDE) + cx * 4];
             *(uint32_t *)yp = (uint32_t)yy[0] | ((uint32_t)yy[1] << 8) | ((uint32_t)yy[2] << 16) | ((uint32_t)yy[3] << 24);
             *(uint32_t *)(yp + YT_STRIDE) =
                 (uint32_t)yy[4] | ((uint32_t)yy[5] << 8) | ((uint32_t)yy[6] << 16) | ((uint32_t)yy[7] << 24);
@@ -557,10 +561,11 @@ __device__ __forceinline__ void jpeg_load_tiles_wide(const JpegDevJob &job, uint
             const uint32_t cb1 = (uint32_t)(cb[2] + cb[3] + cb[6] + cb[7] + 2) >> 2;
             const uint32_t cr0 = (uint32_t)(cr[0] + cr[1] + cr[4] + cr[5] + 1) >> 2;
             const uint32_t cr1 = (uint32_t)(cr[2] + cr[3] + cr[6] + cr[7] + 2) >> 2;
-            const int co = __mul24(qy, CT_STRIDE) + slot * 8 + (cx & 3) * 2;
+            const int co = __mul24(qy, CT_STRIDE) + cx * 2;
             *(uint16_t *)&cbtile[co] = (uint16_t)(cb0 | (cb1 << 8));
             *(uint16_t *)&crtile[co] = (uint16_t)(cr0 | (cr1 << 8));
         } else {
+            const int slot = cx >> 2;
             const int mcx = slot == 0 ? hx : mx0 + slot - 1;
             const int mcy = slot == 0 ? hy : my;
             jpeg_quad_edge<FMT>(job, ytile, cbtile, crtile, slot, (cx & 3) * 2, qy, mcx, mcy);
