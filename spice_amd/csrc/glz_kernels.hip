@@ -876,9 +876,25 @@ __device__ __forceinline__ void glz_window_scan(const GlzDevJob &job, const GlzD
                 gok = true;
                 gidist = (uint32_t)idist;
                 gpdist = (uint32_t)pdist;
+                if (MODE == GLZ_MODE_RGB32 && GLZ_K == 8 && maxk == GLZ_K) {
+                    /* eight whole pixels lie ahead: two 16-byte requests instead of eight
+                     * of four bytes -- every request of the wavefront, wide or narrow,
+                     * is a pass through the CU's one address unit over up to 64 lines */
+                    const GLZ_GLOBAL glz_u32x4_u *w16 = (const GLZ_GLOBAL glz_u32x4_u *)(rbase + (size_t)ref * 4);
+                    const glz_u32x4 lo = w16[0], hi = w16[1];
+                    r[0] = lo[0];
+                    r[1] = lo[1];
+                    r[2] = lo[2];
+                    r[3] = lo[3];
+                    r[GLZ_K - 4] = hi[0];
+                    r[GLZ_K - 3] = hi[1];
+                    r[GLZ_K - 2] = hi[2];
+                    r[GLZ_K - 1] = hi[3];
+                } else {
 #pragma unroll
-                for (int k = 0; k < GLZ_K; k++) {
-                    r[k] = glz_load_px<MODE>(rbase, ref + (k < maxk ? k : 0));
+                    for (int k = 0; k < GLZ_K; k++) {
+                        r[k] = glz_load_px<MODE>(rbase, ref + (k < maxk ? k : 0));
+                    }
                 }
             }
         }
