@@ -36,7 +36,7 @@ struct JpegDevJob {
     int32_t mcu_cols, mcu_rows, strips_per_row, nstrips;
     int32_t yb_w, yb_h;                 /* real luma blocks per row / column */
     int32_t div_y[64], div_c[64];       /* jcdctmgr divisors, natural order */
-    float rcp_y[64], rcp_c[64];         /* 1 / divisor */
+    float rcp_y[64], rcp_c[64];         /* 1 / divisor, rounded down by a part in 2^20 */
     uint8_t *out;
     uint32_t out_cap;
     uint32_t hdr_len;

@@ -211,8 +211,10 @@ bool fill_job(JpegDevJob *j, const void *pixels, int format, int width, int heig
             j->div_y[i] = (int32_t)qy[i] << 3;
             j->div_c[i] = (int32_t)qc[i] << 3;
         }
-        j->rcp_y[i] = 1.0f / (float)j->div_y[i];
-        j->rcp_c[i] = 1.0f / (float)j->div_c[i];
+        /* rounded down a little: the kernel's quotient estimate is then never above
+         * the true one (and at most one below it), so one correction does */
+        j->rcp_y[i] = (float)((1.0 / (double)j->div_y[i]) * (1.0 - 1.0 / 1048576.0));
+        j->rcp_c[i] = (float)((1.0 / (double)j->div_c[i]) * (1.0 - 1.0 / 1048576.0));
     }
     j->hdr_len = (uint32_t)build_header(width, height, qy, qc, j->header);
     j->out = (uint8_t *)out;

@@ -202,16 +202,15 @@ __device__ __forceinline__ void jpeg_fdct(int (&c)[64])
     }
 }
 
-/* libjpeg jcdctmgr.c forward_DCT: round-to-nearest division by the divisor */
+/* libjpeg jcdctmgr.c forward_DCT: round-to-nearest division by the divisor.
+ * rcp is 1/d less about one part in 2^20 (the host rounds it down): with a < 2^17
+ * the estimate a x rcp, itself rounded by 2^-24, stays below a/d and within 0.13
+ * of it, so its integer part is the quotient or one less. */
 __device__ __forceinline__ int jpeg_quant(int v, int d, float rcp)
 {
     const unsigned a = (unsigned)(v < 0 ? -v : v) + ((unsigned)d >> 1);
     unsigned q = (unsigned)((float)a * rcp);
-    int rem = (int)(a - __umul24(q, (unsigned)d));
-    if (rem < 0) {
-        q--;
-        rem += d;
-    }
+    const int rem = (int)(a - __umul24(q, (unsigned)d));
     if (rem >= d) {
         q++;
     }

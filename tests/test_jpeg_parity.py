@@ -117,6 +117,20 @@ def test_sim_negative_stride_and_capacity(sim, oracle):
     run_capacity_error(sim)
 
 
+def test_quantiser_reciprocal_is_one_sided():
+    """the arithmetic claim behind jpeg_quant (jpeg_kernels.hip) and the table jpeg_host.cpp fills:
+    with 1/d rounded down by a part in 2^20, trunc(float(a) * rcp) is floor(a / d) or one less,
+    for every dividend below 2^17 and every divisor a quantisation table can hold"""
+    a = np.arange(0, 1 << 17, dtype=np.uint32)
+    af = a.astype(np.float32)
+    for d in range(1, 4200):
+        rcp = np.float32((1.0 / d) * (1.0 - 1.0 / 1048576.0))
+        q = (af * rcp).astype(np.uint32)
+        rem = a.astype(np.int64) - q.astype(np.int64) * d
+        assert (rem >= 0).all() and (rem < 2 * d).all(), d
+        assert np.array_equal(q + (rem >= d), a // d), d
+
+
 # ------------------------------------------------------------------------ GPU
 @pytest.mark.gpu
 def test_gpu_golden_up_to_720p(gpu, oracle):
