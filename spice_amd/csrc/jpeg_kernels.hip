@@ -218,6 +218,16 @@ __device__ __forceinline__ int jpeg_quant(int v, int d, float rcp)
 }
 
 /* ---------------------------------------------------------------- Huffman */
+/* the n low bits of x (n < 32; none for n = 0): one bit-field extract */
+__device__ __forceinline__ uint32_t jpeg_low_bits(uint32_t x, int n)
+{
+#ifdef SPICE_WAVE_SIM
+    return x & ((1u << n) - 1);
+#else
+    return __builtin_amdgcn_ubfe(x, 0u, (uint32_t)n);
+#endif
+}
+
 /* packed table entry: size << 16 | code */
 __device__ __forceinline__ int jpeg_nbits(int a)
 {
@@ -827,7 +837,7 @@ __device__ __forceinline__ void jpeg_strip_body(const JpegDevJob &job, const uin
                         }
                         const int t = v < 0 ? -v : v;
                         const int nb = 32 - __clz(t);
-                        const uint32_t vbits = (uint32_t)(v + (v >> 31)) & ((1u << nb) - 1);
+                        const uint32_t vbits = jpeg_low_bits((uint32_t)(v + (v >> 31)), nb);
                         if (k == 0) {
                             const uint32_t e = huff[dc_off + nb];
                             len = (int)(e >> 16) + nb;
@@ -872,7 +882,7 @@ __device__ __forceinline__ void jpeg_strip_body(const JpegDevJob &job, const uin
                             const int v = (int)(int16_t)coef16[(m0 * 6 + lane) * (JCOEF_STRIDE * 2) + k];
                             const int t = v < 0 ? -v : v;
                             const int nb = 32 - __clz(t);
-                            const uint32_t vbits = (uint32_t)(v + (v >> 31)) & ((1u << nb) - 1);
+                            const uint32_t vbits = jpeg_low_bits((uint32_t)(v + (v >> 31)), nb);
                             if (k == 0) {
                                 const uint32_t e = huff[dc_off + nb];
                                 jpeg_ring_put(ring, pos, ((e & 0xffff) << nb) | vbits, (int)(e >> 16) + nb);
@@ -900,7 +910,7 @@ __device__ __forceinline__ void jpeg_strip_body(const JpegDevJob &job, const uin
                 for (uint32_t i = (uint32_t)lane; i < (total + 31) >> 5; i += 64) {
                     const uint32_t w = ring[i];
                     ring[i] = 0;
-                    out_words[i] = (w >> 24) | ((w >> 8) & 0xff00) | ((w << 8) & 0xff0000) | (w << 24);
+                    out_words[i] = __builtin_bswap32(w);
                 }
                 __builtin_amdgcn_wave_barrier();
                 bits = total;
@@ -923,7 +933,7 @@ __device__ __forceinline__ void jpeg_strip_body(const JpegDevJob &job, const uin
             const uint64_t nz = __ballot(v != 0) & ~1ull;
             const int t = v < 0 ? -v : v, t2 = v + (v >> 31);
             const int nb = 32 - __clz(t);
-            const uint32_t vbits = (uint32_t)t2 & ((1u << nb) - 1);
+            const uint32_t vbits = jpeg_low_bits((uint32_t)t2, nb);
             uint32_t total;
             if (nz == 0) {
                 /* no AC coefficient at all (about every other block of video content):
@@ -974,7 +984,7 @@ __device__ __forceinline__ void jpeg_strip_body(const JpegDevJob &job, const uin
                 for (uint32_t i = flushed + (uint32_t)lane; i < upto; i += 64) {
                     const uint32_t w = ring[i & (JRING_WORDS - 1)];
                     ring[i & (JRING_WORDS - 1)] = 0;
-                    out_words[i] = (w >> 24) | ((w >> 8) & 0xff00) | ((w << 8) & 0xff0000) | (w << 24);
+                    out_words[i] = __builtin_bswap32(w);
                 }
                 flushed = upto;
                 __builtin_amdgcn_wave_barrier();
