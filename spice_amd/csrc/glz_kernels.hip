@@ -1019,12 +1019,14 @@ __device__ __forceinline__ uint64_t glz_tail_bits(int t0, int t1, int q)
 #define GLZ_W_LEN_DEEP 31      /* an older store to the slot may exist */
 
 template <int MODE>
-__device__ __forceinline__ uint32_t glz_quarter_words(int Q, int lane)
+__device__ __forceinline__ uint32_t glz_quarter_words(int Q, int lane, uint32_t &o_a, uint32_t &o_b)
 {
     GlzShared &sh = glz_sh;
     const uint32_t *ins32 = (const uint32_t *)sh.ins;
     const int p = Q * 64 + lane;
     const uint32_t a = sh.infoA[p], b = sh.infoB[p];
+    o_a = a; /* the walk asks for them by lane index instead of going to LDS again */
+    o_b = b;
     if (!(a & GLZ_A_ACT)) {
         return GLZ_W_SLOW;
     }
@@ -1180,12 +1182,11 @@ __device__ __forceinline__ void glz_fast_stops(uint32_t W, int &l, uint64_t &ins
  * (lane l, bit q = position 64 q + l). */
 template <int MODE>
 __device__ __forceinline__ int glz_resolve_general(const GlzDevJob &job, const GLZ_GLOBAL uint8_t *base,
-                                                   int ip, int ip_bound, int i, uint64_t ins,
-                                                   uint32_t vfl, uint64_t q0, uint64_t q1, uint64_t q2,
-                                                   uint64_t q3, int lane, bool *o_run)
+                                                   int ip, int ip_bound, int i, uint32_t a, uint32_t b,
+                                                   uint64_t ins, uint32_t vfl, uint64_t q0, uint64_t q1,
+                                                   uint64_t q2, uint64_t q3, int lane, bool *o_run)
 {
     GlzShared &sh = glz_sh;
-    const uint32_t a = glz_uniform(sh.infoA[i]);
     const int l = i & 63, Q = i >> 6;
     const int anchor = ip + i;
     int len = 0;
@@ -1225,7 +1226,6 @@ __device__ __forceinline__ int glz_resolve_general(const GlzDevJob &job, const G
             } else if (!(a & GLZ_A_P2V)) {
                 table = true;
             } else {
-                const uint32_t b = glz_uniform(sh.infoB[i]);
                 const int c2 = (int)(b & 255u);
                 const bool st2 = (a & GLZ_A_P2SAME) ? (ins >> (c2 & 63)) & 1
                                                     : (glz_readlane(vfl, c2 & 63) >> (c2 >> 6)) & 1;
@@ -1335,7 +1335,8 @@ __device__ __forceinline__ void glz_window_resolve(const GlzDevJob &job, uint32_
         }
         uint64_t ins = glz_tail_bits(t0, t1, Q), stops = 0, ms = 0, slow = 0;
         __builtin_amdgcn_wave_barrier(); /* lane 0's marks of the finished quarters are read below */
-        const uint32_t W = glz_quarter_words<MODE>(Q, lane);
+        uint32_t qa, qb; /* this lane's position: the scan's two result words */
+        const uint32_t W = glz_quarter_words<MODE>(Q, lane, qa, qb);
         int l = i & 63;
         int last_len = 0;
 
@@ -1353,7 +1354,8 @@ __device__ __forceinline__ void glz_window_resolve(const GlzDevJob &job, uint32_
             }
             /* the others: no stop here at all, a run, a compare that goes on
              * past GLZ_K, a slot whose nearest two predecessors were skipped */
-            if (!(glz_uniform(sh.infoA[Q * 64 + l]) & GLZ_A_ACT)) {
+            const uint32_t sa = glz_readlane(qa, l), sb = glz_readlane(qb, l);
+            if (!(sa & GLZ_A_ACT)) {
                 open = false; /* the segment's last stops are behind us */
                 break;
             }
@@ -1363,8 +1365,8 @@ __device__ __forceinline__ void glz_window_resolve(const GlzDevJob &job, uint32_
 #ifdef GLZ_STAMPS
                 const long long g0 = STAMP();
 #endif
-                const int len = glz_resolve_general<MODE>(job, base, ip, ip_bound, Q * 64 + l, ins, vfl, q0, q1,
-                                                          q2, q3, lane, &run);
+                const int len = glz_resolve_general<MODE>(job, base, ip, ip_bound, Q * 64 + l, sa, sb, ins, vfl,
+                                                          q0, q1, q2, q3, lane, &run);
 #ifdef GLZ_STAMPS
                 sh.st_gen += STAMP() - g0;
                 sh.st_ngen++;
