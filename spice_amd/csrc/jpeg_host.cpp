@@ -7,6 +7,7 @@
  * (server/mjpeg_encoder.h, server/jpeg_encoder.h) and the device-resident
  * batch interface.
  */
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -179,6 +180,16 @@ int format_bpp(int fmt)
     }
 }
 
+/* the single-precision number at or just above 1 / d */
+static float recip_not_below(int32_t d)
+{
+    float r = (float)(1.0 / (double)d);
+    if ((double)r * (double)d < 1.0) {
+        r = nextafterf(r, 2.0f);
+    }
+    return r;
+}
+
 /* Fills everything of a device job that depends only on the parameters. */
 bool fill_job(JpegDevJob *j, const void *pixels, int format, int width, int height, long stride,
               int quality, int dct, void *out, uint32_t out_cap)
@@ -215,6 +226,16 @@ bool fill_job(JpegDevJob *j, const void *pixels, int format, int width, int heig
          * the true one (and at most one below it), so one correction does */
         j->rcp_y[i] = (float)((1.0 / (double)j->div_y[i]) * (1.0 - 1.0 / 1048576.0));
         j->rcp_c[i] = (float)((1.0 / (double)j->div_c[i]) * (1.0 - 1.0 / 1048576.0));
+        if (dct) {
+            /* the IFAST kernel quantises in single precision and truncates the product:
+             * its reciprocal must not lie below 1/d */
+            j->rcp_y[i] = recip_not_below(j->div_y[i]);
+            j->rcp_c[i] = recip_not_below(j->div_c[i]);
+            j->qthr_y[i] = (float)(j->div_y[i] - (j->div_y[i] >> 1));
+            j->qthr_c[i] = (float)(j->div_c[i] - (j->div_c[i] >> 1));
+            j->qhalf_y[i] = (float)(j->div_y[i] >> 1);
+            j->qhalf_c[i] = (float)(j->div_c[i] >> 1);
+        }
     }
     j->hdr_len = (uint32_t)build_header(width, height, qy, qc, j->header);
     j->out = (uint8_t *)out;

@@ -180,6 +180,83 @@ __device__ __forceinline__ void jpeg_ifast_1d(int &d0, int &d1, int &d2, int &d3
 }
 
 #define J8(a, o, s) a[o], a[o + s], a[o + 2 * s], a[o + 3 * s], a[o + 4 * s], a[o + 5 * s], a[o + 6 * s], a[o + 7 * s]
+/* The same pass on two independent 8-point rows (or columns) at once, one in each half
+ * of a pair of single-precision values (v_pk_add_f32 / v_pk_mul_f32).  Exact: the
+ * operands are integers below 2^15, every product with a constant (at most 669) stays
+ * below 2^24, c / 256 is a power-of-two scaling, and the shift by 8 of the integer code,
+ * which rounds towards minus infinity, is the floor. */
+typedef float jf2 __attribute__((vector_size(8)));
+
+__device__ __forceinline__ jf2 jpeg_f2(float a, float b)
+{
+    jf2 r;
+    r[0] = a;
+    r[1] = b;
+    return r;
+}
+
+__device__ __forceinline__ jf2 jpeg_mulshift8(jf2 v, float c256)
+{
+    const jf2 m = v * jpeg_f2(c256, c256);
+    return jpeg_f2(__builtin_floorf(m[0]), __builtin_floorf(m[1]));
+}
+
+__device__ __forceinline__ void jpeg_ifast_1d_f2(jf2 &d0, jf2 &d1, jf2 &d2, jf2 &d3, jf2 &d4, jf2 &d5,
+                                                 jf2 &d6, jf2 &d7)
+{
+    const jf2 t0 = d0 + d7, t7 = d0 - d7, t1 = d1 + d6, t6 = d1 - d6;
+    const jf2 t2 = d2 + d5, t5 = d2 - d5, t3 = d3 + d4, t4 = d3 - d4;
+    jf2 t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
+    d0 = t10 + t11;
+    d4 = t10 - t11;
+    const jf2 z1 = jpeg_mulshift8(t12 + t13, 181.0f / 256.0f);
+    d2 = t13 + z1;
+    d6 = t13 - z1;
+    t10 = t4 + t5;
+    t11 = t5 + t6;
+    t12 = t6 + t7;
+    const jf2 z5 = jpeg_mulshift8(t10 - t12, 98.0f / 256.0f);
+    const jf2 z2 = jpeg_mulshift8(t10, 139.0f / 256.0f) + z5;
+    const jf2 z4 = jpeg_mulshift8(t12, 334.0f / 256.0f) + z5;
+    const jf2 z3 = jpeg_mulshift8(t11, 181.0f / 256.0f);
+    const jf2 z11 = t7 + z3, z13 = t7 - z3;
+    d5 = z13 + z2;
+    d3 = z13 - z2;
+    d1 = z11 + z4;
+    d7 = z11 - z4;
+}
+
+/* jfdctfst.c on a block held as 32 pairs: on entry p[rp * 8 + k] = samples (2 rp, k) and
+ * (2 rp + 1, k), unsigned (the level shift of 128 a sample reaches nothing but the DC
+ * term -- every product is taken of a difference in which it cancels -- and is taken
+ * off there, 64 x 128); on return p[r * 4 + kp] = coefficients (r, 2 kp) and (r, 2 kp + 1). */
+__device__ __forceinline__ void jpeg_fdct_ifast_f2(jf2 (&p)[32])
+{
+#pragma unroll
+    for (int rp = 0; rp < 4; rp++) {
+        jpeg_ifast_1d_f2(J8(p, rp * 8, 1));
+    }
+    /* rows paired -> columns paired: a 2 x 2 transpose of every pair of pairs */
+    jf2 q[32];
+#pragma unroll
+    for (int rp = 0; rp < 4; rp++) {
+#pragma unroll
+        for (int kp = 0; kp < 4; kp++) {
+            const jf2 a = p[rp * 8 + 2 * kp], b = p[rp * 8 + 2 * kp + 1];
+            q[(2 * rp) * 4 + kp] = jpeg_f2(a[0], b[0]);
+            q[(2 * rp + 1) * 4 + kp] = jpeg_f2(a[1], b[1]);
+        }
+    }
+#pragma unroll
+    for (int kp = 0; kp < 4; kp++) {
+        jpeg_ifast_1d_f2(J8(q, kp, 4));
+    }
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+        p[i] = q[i];
+    }
+    p[0][0] -= 8192.0f;
+}
 
 template <bool IFAST>
 __device__ __forceinline__ void jpeg_fdct(int (&c)[64])
@@ -654,8 +731,11 @@ __device__ __forceinline__ void jpeg_strip_body(const JpegDevJob &job, const uin
     /* ---- phase 2: one lane per block.  Luma lanes are ordered so that a wave
      * reads consecutive 8-byte columns of one tile row. */
     int c[64];
+    jf2 pf[32];            /* the block as pairs of floats (IFAST) */
     int slot = 0, bidx = 0; /* block's MCU slot and its index 0..5 inside the MCU */
     bool have = false, real = false;
+    const uint8_t *src = pool; /* the block's first row in its tile */
+    int rstride = 0;
     if (tid < 4 * ns) {
         const int yi = tid / (2 * ns), col = tid - yi * 2 * ns;
         slot = col >> 1;
@@ -664,10 +744,38 @@ __device__ __forceinline__ void jpeg_strip_body(const JpegDevJob &job, const uin
         have = true;
         const int mcx = slot == 0 ? hx : mx0 + slot - 1, mcy = slot == 0 ? hy : my;
         real = (mcy * 2 + yi) < job.yb_h && (mcx * 2 + xi) < job.yb_w;
-        if (real) {
+        src = &ytile[(yi * 8) * YT_STRIDE + col * 8];
+        rstride = YT_STRIDE;
+    } else if (tid < 6 * ns) {
+        const int k = tid - 4 * ns;
+        const bool is_cr = k >= ns;
+        slot = is_cr ? k - ns : k;
+        bidx = is_cr ? 5 : 4;
+        have = true;
+        real = true;
+        src = (is_cr ? crtile : cbtile) + slot * 8;
+        rstride = CT_STRIDE;
+    }
+    if (have && real) {
+        if (IFAST) {
+            /* rows two at a time: a pair holds the same column of both */
+#pragma unroll
+            for (int rp = 0; rp < 4; rp++) {
+                const uint2 v = *(const uint2 *)(src + (2 * rp) * rstride);
+                const uint2 w = *(const uint2 *)(src + (2 * rp + 1) * rstride);
+                pf[rp * 8 + 0] = jpeg_f2((float)(v.x & 0xff), (float)(w.x & 0xff));
+                pf[rp * 8 + 1] = jpeg_f2((float)((v.x >> 8) & 0xff), (float)((w.x >> 8) & 0xff));
+                pf[rp * 8 + 2] = jpeg_f2((float)((v.x >> 16) & 0xff), (float)((w.x >> 16) & 0xff));
+                pf[rp * 8 + 3] = jpeg_f2((float)(v.x >> 24), (float)(w.x >> 24));
+                pf[rp * 8 + 4] = jpeg_f2((float)(v.y & 0xff), (float)(w.y & 0xff));
+                pf[rp * 8 + 5] = jpeg_f2((float)((v.y >> 8) & 0xff), (float)((w.y >> 8) & 0xff));
+                pf[rp * 8 + 6] = jpeg_f2((float)((v.y >> 16) & 0xff), (float)((w.y >> 16) & 0xff));
+                pf[rp * 8 + 7] = jpeg_f2((float)(v.y >> 24), (float)(w.y >> 24));
+            }
+        } else {
 #pragma unroll
             for (int r = 0; r < 8; r++) {
-                const uint2 v = *(const uint2 *)&ytile[(yi * 8 + r) * YT_STRIDE + col * 8];
+                const uint2 v = *(const uint2 *)(src + r * rstride);
                 c[r * 8 + 0] = (int)(v.x & 0xff) - 128;
                 c[r * 8 + 1] = (int)((v.x >> 8) & 0xff) - 128;
                 c[r * 8 + 2] = (int)((v.x >> 16) & 0xff) - 128;
@@ -678,66 +786,83 @@ __device__ __forceinline__ void jpeg_strip_body(const JpegDevJob &job, const uin
                 c[r * 8 + 7] = (int)(v.y >> 24) - 128;
             }
         }
-    } else if (tid < 6 * ns) {
-        const int k = tid - 4 * ns;
-        const bool is_cr = k >= ns;
-        slot = is_cr ? k - ns : k;
-        bidx = is_cr ? 5 : 4;
-        have = true;
-        real = true;
-        const uint8_t *tile = is_cr ? crtile : cbtile;
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const uint2 v = *(const uint2 *)&tile[r * CT_STRIDE + slot * 8];
-            c[r * 8 + 0] = (int)(v.x & 0xff) - 128;
-            c[r * 8 + 1] = (int)((v.x >> 8) & 0xff) - 128;
-            c[r * 8 + 2] = (int)((v.x >> 16) & 0xff) - 128;
-            c[r * 8 + 3] = (int)(v.x >> 24) - 128;
-            c[r * 8 + 4] = (int)(v.y & 0xff) - 128;
-            c[r * 8 + 5] = (int)((v.y >> 8) & 0xff) - 128;
-            c[r * 8 + 6] = (int)((v.y >> 16) & 0xff) - 128;
-            c[r * 8 + 7] = (int)(v.y >> 24) - 128;
-        }
     }
     if (slot == 0 && !has_halo) {
         have = false;
     }
     __syncthreads(); /* last read of the tiles; the coefficients overwrite them */
     if (have && real) {
-        jpeg_fdct<IFAST>(c);
+        if (IFAST) {
+            jpeg_fdct_ifast_f2(pf);
+        } else {
+            jpeg_fdct<false>(c);
+        }
     }
     /* The divisors come through the scalar unit, a table at a time: luma lanes
      * first, then chroma lanes (only one wavefront of the four holds both), so
-     * no vector register is spent on the 128 constants. */
+     * no vector register is spent on the constants. */
 #pragma unroll
     for (int pass = 0; pass < 2; pass++) {
         const bool mine = have && real && ((bidx < 4) == (pass == 0));
         if (__ballot(mine) == 0) {
             continue;
         }
-        const JPEG_CONST int *dv = (const JPEG_CONST int *)(uintptr_t)(pass == 0 ? job.div_y : job.div_c);
-        const JPEG_CONST float *rc = (const JPEG_CONST float *)(uintptr_t)(pass == 0 ? job.rcp_y : job.rcp_c);
-        /* |v| + d/2 < d rounds to zero; away from the low frequencies that holds
-         * for every block of the wavefront more often than not, and the division
-         * is skipped for all of them at once.  Lanes of the other table answer the
-         * votes with a constant "no": the compiler drops that loop (an inactive
-         * lane's vote reads as zero anyway), while the CPU wave simulator, where a
-         * vote waits for every lane of the wavefront, needs the calls to pair up. */
-        if (mine) {
+        /* A coefficient below its threshold (|v| + d/2 < d) rounds to zero; away from
+         * the low frequencies that holds for every block of the wavefront more often
+         * than not, and the division is skipped for all of them at once.  Lanes of the
+         * other table answer the votes with a constant "no": the compiler drops that
+         * loop (an inactive lane's vote reads as zero anyway), while the CPU wave
+         * simulator, where a vote waits for every lane of the wavefront, needs the
+         * calls to pair up. */
+        if (IFAST) {
+            /* jcdctmgr.c's sign(v) x floor((|v| + d/2) / d) on the pairs the DCT left:
+             * a = v + copysign(d/2, v); a x rcp, with rcp the float at or just above
+             * 1/d, lies at or above a/d and below the next integer (|a| < 2^18), so
+             * truncating it is the division; two coefficients share the add and the
+             * multiply */
+            const JPEG_CONST float *th = (const JPEG_CONST float *)(uintptr_t)(pass == 0 ? job.qthr_y : job.qthr_c);
+            const JPEG_CONST float *hf = (const JPEG_CONST float *)(uintptr_t)(pass == 0 ? job.qhalf_y : job.qhalf_c);
+            const JPEG_CONST float *rc = (const JPEG_CONST float *)(uintptr_t)(pass == 0 ? job.rcp_y : job.rcp_c);
+            if (mine) {
 #pragma unroll
-            for (int i = 0; i < 64; i++) {
-                const int d = dv[i];
-                const int thr = d - (d >> 1);
-                const bool stays = (unsigned)(c[i] + thr - 1) >= (unsigned)(2 * thr - 1);
-                if (i > 0 && __ballot(stays) == 0) {
-                    c[i] = 0;
-                } else {
-                    c[i] = jpeg_quant(c[i], d, rc[i]);
+                for (int j = 0; j < 32; j++) {
+                    const jf2 t = pf[j];
+                    const bool stays = __builtin_fabsf(t[0]) >= th[2 * j] || __builtin_fabsf(t[1]) >= th[2 * j + 1];
+                    if (j > 0 && __ballot(stays) == 0) {
+                        c[2 * j] = 0;
+                        c[2 * j + 1] = 0;
+                    } else {
+                        const jf2 a = t + jpeg_f2(__builtin_copysignf(hf[2 * j], t[0]),
+                                                  __builtin_copysignf(hf[2 * j + 1], t[1]));
+                        const jf2 q = a * jpeg_f2(rc[2 * j], rc[2 * j + 1]);
+                        c[2 * j] = (int)q[0];
+                        c[2 * j + 1] = (int)q[1];
+                    }
+                }
+            } else {
+                for (int j = 1; j < 32; j++) {
+                    (void)__ballot(false);
                 }
             }
         } else {
-            for (int i = 1; i < 64; i++) {
-                (void)__ballot(false);
+            const JPEG_CONST int *dv = (const JPEG_CONST int *)(uintptr_t)(pass == 0 ? job.div_y : job.div_c);
+            const JPEG_CONST float *rc = (const JPEG_CONST float *)(uintptr_t)(pass == 0 ? job.rcp_y : job.rcp_c);
+            if (mine) {
+#pragma unroll
+                for (int i = 0; i < 64; i++) {
+                    const int d = dv[i];
+                    const int thr = d - (d >> 1);
+                    const bool stays = (unsigned)(c[i] + thr - 1) >= (unsigned)(2 * thr - 1);
+                    if (i > 0 && __ballot(stays) == 0) {
+                        c[i] = 0;
+                    } else {
+                        c[i] = jpeg_quant(c[i], d, rc[i]);
+                    }
+                }
+            } else {
+                for (int i = 1; i < 64; i++) {
+                    (void)__ballot(false);
+                }
             }
         }
     }
@@ -1337,7 +1462,7 @@ void jpeg_launch(const JpegDevJob *jobs, int njobs, int max_groups, bool any_isl
 #define JPEG_NA_MAX_STRIPS 1024          /* e.g. 1920 x 1088: 12 strips x 68 MCU rows = 816 */
 #define JPEG_NA_MAX_OUT (4u << 20)       /* largest out_capacity */
 #define JPEG_NA_STRIP_STRIDE (JPEG_MCU_SLOT_BYTES * JPEG_STRIP_MCUS)
-#define JPEG_NA_OFF_RESULT 2048u
+#define JPEG_NA_OFF_RESULT 3072u
 #define JPEG_NA_OFF_HUFF 4096u
 #define JPEG_NA_OFF_BITS 8192u
 #define JPEG_NA_OFF_BITOFF 12288u
