@@ -53,6 +53,12 @@
     13, 6, 7, 14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, \
     52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63
 
+/* where natural-order coefficient i goes in the zigzag sequence */
+#define JIZZ_LIST \
+    0, 1, 5, 6, 14, 15, 27, 28, 2, 4, 7, 13, 16, 26, 29, 42, 3, 8, 12, 17, 25, 30, 41, 43, 9, 11, 18, \
+    24, 31, 40, 44, 53, 10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38, 46, 51, 55, 60, 21, 34, 37, \
+    47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63
+
 /* ---------------------------------------------------------------- pixels */
 /* Source pixel (x, y) as stored, and its conversion to r | g << 8 | b << 16
  * (converters of mjpeg_encoder.c:236-259).  FMT: 6 x1r5g5b5, 7 b,g,r bytes,
@@ -186,6 +192,22 @@ __device__ __forceinline__ void jpeg_ifast_1d(int &d0, int &d1, int &d2, int &d3
  * below 2^24, c / 256 is a power-of-two scaling, and the shift by 8 of the integer code,
  * which rounds towards minus infinity, is the floor. */
 typedef float jf2 __attribute__((vector_size(8)));
+
+typedef float jf8 __attribute__((vector_size(32), aligned(4))); /* eight constants of a table row, wherever the row starts */
+
+__device__ __forceinline__ uint32_t jpeg_fbits(float f)
+{
+    union { float f; uint32_t u; } x;
+    x.f = f;
+    return x.u;
+}
+
+__device__ __forceinline__ float jpeg_bitsf(uint32_t u)
+{
+    union { float f; uint32_t u; } x;
+    x.u = u;
+    return x.f;
+}
 
 __device__ __forceinline__ jf2 jpeg_f2(float a, float b)
 {
@@ -677,7 +699,9 @@ __device__ __forceinline__ void jpeg_strip_body(const JpegDevJob &job, const uin
     /* the pixel tiles are dead once every lane holds its block in registers, so the
      * coefficients take their place: with the tables and bit rings 39 KB per workgroup, four workgroups per CU */
     constexpr int kTileBytes = 16 * YT_STRIDE + 2 * 8 * CT_STRIDE;
-    constexpr int kCoefBytes = JG_MCUS * 6 * JCOEF_STRIDE * 4;
+    /* one MCU's worth more than the group has: where the halo MCU's lanes put the
+     * coefficients nobody reads (only its DC values are wanted) */
+    constexpr int kCoefBytes = (JG_MCUS + 1) * 6 * JCOEF_STRIDE * 4;
     __shared__ __align__(16) uint8_t pool[kCoefBytes > kTileBytes ? kCoefBytes : kTileBytes];
     uint8_t *const ytile = pool;
     uint8_t *const cbtile = pool + 16 * YT_STRIDE;
@@ -820,27 +844,52 @@ __device__ __forceinline__ void jpeg_strip_body(const JpegDevJob &job, const uin
              * 1/d, lies at or above a/d and below the next integer (|a| < 2^18), so
              * truncating it is the division; two coefficients share the add and the
              * multiply */
-            const JPEG_CONST float *th = (const JPEG_CONST float *)(uintptr_t)(pass == 0 ? job.qthr_y : job.qthr_c);
-            const JPEG_CONST float *hf = (const JPEG_CONST float *)(uintptr_t)(pass == 0 ? job.qhalf_y : job.qhalf_c);
-            const JPEG_CONST float *rc = (const JPEG_CONST float *)(uintptr_t)(pass == 0 ? job.rcp_y : job.rcp_c);
+            const JPEG_CONST jf8 *th = (const JPEG_CONST jf8 *)(uintptr_t)(pass == 0 ? job.qthr_y : job.qthr_c);
+            const JPEG_CONST jf8 *hf = (const JPEG_CONST jf8 *)(uintptr_t)(pass == 0 ? job.qhalf_y : job.qhalf_c);
+            const JPEG_CONST jf8 *rc = (const JPEG_CONST jf8 *)(uintptr_t)(pass == 0 ? job.rcp_y : job.rcp_c);
             if (mine) {
+                /* everything but the sign bit, in a vector register: the sign transfer
+                 * below is then one v_bfi_b32 whose only scalar operand is d/2 */
+                uint32_t magn = 0x7fffffffu;
+#ifndef SPICE_WAVE_SIM
+                asm volatile("" : "+v"(magn));
+#endif
+                /* The quotients go straight to the block's place in LDS, 16 bits each at
+                 * its zigzag position, as they are made: none of them stays in a
+                 * register waiting for its neighbour in zigzag order. */
+                constexpr int izz[64] = {JIZZ_LIST};
+                uint16_t *dst16 = (uint16_t *)(coef + ((slot > 0 ? slot - 1 : JG_MCUS) * 6 + bidx) * JCOEF_STRIDE);
 #pragma unroll
-                for (int j = 0; j < 32; j++) {
-                    const jf2 t = pf[j];
-                    const bool stays = __builtin_fabsf(t[0]) >= th[2 * j] || __builtin_fabsf(t[1]) >= th[2 * j + 1];
-                    if (j > 0 && __ballot(stays) == 0) {
-                        c[2 * j] = 0;
-                        c[2 * j + 1] = 0;
-                    } else {
-                        const jf2 a = t + jpeg_f2(__builtin_copysignf(hf[2 * j], t[0]),
-                                                  __builtin_copysignf(hf[2 * j + 1], t[1]));
-                        const jf2 q = a * jpeg_f2(rc[2 * j], rc[2 * j + 1]);
-                        c[2 * j] = (int)q[0];
-                        c[2 * j + 1] = (int)q[1];
+                for (int g = 0; g < 8; g++) {
+                    /* a row of eight coefficients: its constants in three scalar loads */
+                    const jf8 th8 = th[g], hf8 = hf[g], rc8 = rc[g];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int j = g * 4 + u;
+                        const jf2 t = pf[j];
+                        const uint64_t stay0 = __ballot(__builtin_fabsf(t[0]) >= th8[2 * u]);
+                        const uint64_t stay1 = __ballot(__builtin_fabsf(t[1]) >= th8[2 * u + 1]);
+                        if (j > 0 && (stay0 | stay1) == 0) {
+                            dst16[izz[2 * j]] = 0;
+                            dst16[izz[2 * j + 1]] = 0;
+                        } else {
+                            /* sign of t over d/2: t ^ ((h ^ t) & magn), one v_bfi_b32 */
+                            const uint32_t b0 = jpeg_fbits(t[0]), b1 = jpeg_fbits(t[1]);
+                            const uint32_t s0 = b0 ^ ((jpeg_fbits(hf8[2 * u]) ^ b0) & magn);
+                            const uint32_t s1 = b1 ^ ((jpeg_fbits(hf8[2 * u + 1]) ^ b1) & magn);
+                            const jf2 a = t + jpeg_f2(jpeg_bitsf(s0), jpeg_bitsf(s1));
+                            const jf2 q = a * jpeg_f2(rc8[2 * u], rc8[2 * u + 1]);
+                            const int q0 = (int)q[0], q1 = (int)q[1];
+                            dst16[izz[2 * j]] = (uint16_t)q0;
+                            dst16[izz[2 * j + 1]] = (uint16_t)q1;
+                            if (j == 0) {
+                                c[0] = q0;
+                            }
+                        }
                     }
                 }
             } else {
-                for (int j = 1; j < 32; j++) {
+                for (int j = 0; j < 64; j++) {
                     (void)__ballot(false);
                 }
             }
@@ -868,13 +917,22 @@ __device__ __forceinline__ void jpeg_strip_body(const JpegDevJob &job, const uin
     }
     if (have && real) {
         dcq[slot * 6 + bidx] = c[0];
-    } else {
+    } else if (!IFAST) {
 #pragma unroll
         for (int i = 0; i < 64; i++) {
             c[i] = 0;
         }
     }
-    if (have && slot > 0) {
+    if (IFAST) {
+        /* a dummy block is all zeros (its DC comes out of dcq below) */
+        if (have && !real && slot > 0) {
+            uint32_t *dst = coef + ((slot - 1) * 6 + bidx) * JCOEF_STRIDE;
+#pragma unroll
+            for (int j = 0; j < 32; j++) {
+                dst[j] = 0;
+            }
+        }
+    } else if (have && slot > 0) {
         /* zigzag order, two coefficients per word; a dummy block is all zeros
          * (its DC comes out of dcq below) */
         constexpr int zz[64] = {JZZ_LIST};
