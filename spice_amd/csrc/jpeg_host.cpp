@@ -222,20 +222,14 @@ bool fill_job(JpegDevJob *j, const void *pixels, int format, int width, int heig
             j->div_y[i] = (int32_t)qy[i] << 3;
             j->div_c[i] = (int32_t)qc[i] << 3;
         }
-        /* rounded down a little: the kernel's quotient estimate is then never above
-         * the true one (and at most one below it), so one correction does */
-        j->rcp_y[i] = (float)((1.0 / (double)j->div_y[i]) * (1.0 - 1.0 / 1048576.0));
-        j->rcp_c[i] = (float)((1.0 / (double)j->div_c[i]) * (1.0 - 1.0 / 1048576.0));
-        if (dct) {
-            /* the IFAST kernel quantises in single precision and truncates the product:
-             * its reciprocal must not lie below 1/d */
-            j->rcp_y[i] = recip_not_below(j->div_y[i]);
-            j->rcp_c[i] = recip_not_below(j->div_c[i]);
-            j->qthr_y[i] = (float)(j->div_y[i] - (j->div_y[i] >> 1));
-            j->qthr_c[i] = (float)(j->div_c[i] - (j->div_c[i] >> 1));
-            j->qhalf_y[i] = (float)(j->div_y[i] >> 1);
-            j->qhalf_c[i] = (float)(j->div_c[i] >> 1);
-        }
+        /* the kernel quantises in single precision and truncates the product: its
+         * reciprocal must not lie below 1/d */
+        j->rcp_y[i] = recip_not_below(j->div_y[i]);
+        j->rcp_c[i] = recip_not_below(j->div_c[i]);
+        j->qthr_y[i] = (float)(j->div_y[i] - (j->div_y[i] >> 1));
+        j->qthr_c[i] = (float)(j->div_c[i] - (j->div_c[i] >> 1));
+        j->qhalf_y[i] = (float)(j->div_y[i] >> 1);
+        j->qhalf_c[i] = (float)(j->div_c[i] >> 1);
     }
     j->hdr_len = (uint32_t)build_header(width, height, qy, qc, j->header);
     j->out = (uint8_t *)out;

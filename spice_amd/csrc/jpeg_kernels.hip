@@ -301,21 +301,6 @@ __device__ __forceinline__ void jpeg_fdct(int (&c)[64])
     }
 }
 
-/* libjpeg jcdctmgr.c forward_DCT: round-to-nearest division by the divisor.
- * rcp is 1/d less about one part in 2^20 (the host rounds it down): with a < 2^17
- * the estimate a x rcp, itself rounded by 2^-24, stays below a/d and within 0.13
- * of it, so its integer part is the quotient or one less. */
-__device__ __forceinline__ int jpeg_quant(int v, int d, float rcp)
-{
-    const unsigned a = (unsigned)(v < 0 ? -v : v) + ((unsigned)d >> 1);
-    unsigned q = (unsigned)((float)a * rcp);
-    const int rem = (int)(a - __umul24(q, (unsigned)d));
-    if (rem >= d) {
-        q++;
-    }
-    return v < 0 ? -(int)q : (int)q;
-}
-
 /* ---------------------------------------------------------------- Huffman */
 /* the n low bits of x (n < 32; none for n = 0): one bit-field extract */
 __device__ __forceinline__ uint32_t jpeg_low_bits(uint32_t x, int n)
@@ -820,6 +805,11 @@ __device__ __forceinline__ void jpeg_strip_body(const JpegDevJob &job, const uin
             jpeg_fdct_ifast_f2(pf);
         } else {
             jpeg_fdct<false>(c);
+            /* the quantiser below works on pairs of floats (|coefficient| < 2^16: exact) */
+#pragma unroll
+            for (int j = 0; j < 32; j++) {
+                pf[j] = jpeg_f2((float)c[2 * j], (float)c[2 * j + 1]);
+            }
         }
     }
     /* The divisors come through the scalar unit, a table at a time: luma lanes
@@ -838,108 +828,70 @@ __device__ __forceinline__ void jpeg_strip_body(const JpegDevJob &job, const uin
          * loop (an inactive lane's vote reads as zero anyway), while the CPU wave
          * simulator, where a vote waits for every lane of the wavefront, needs the
          * calls to pair up. */
-        if (IFAST) {
-            /* jcdctmgr.c's sign(v) x floor((|v| + d/2) / d) on the pairs the DCT left:
-             * a = v + copysign(d/2, v); a x rcp, with rcp the float at or just above
-             * 1/d, lies at or above a/d and below the next integer (|a| < 2^18), so
-             * truncating it is the division; two coefficients share the add and the
-             * multiply */
-            const JPEG_CONST jf8 *th = (const JPEG_CONST jf8 *)(uintptr_t)(pass == 0 ? job.qthr_y : job.qthr_c);
-            const JPEG_CONST jf8 *hf = (const JPEG_CONST jf8 *)(uintptr_t)(pass == 0 ? job.qhalf_y : job.qhalf_c);
-            const JPEG_CONST jf8 *rc = (const JPEG_CONST jf8 *)(uintptr_t)(pass == 0 ? job.rcp_y : job.rcp_c);
-            if (mine) {
-                /* everything but the sign bit, in a vector register: the sign transfer
-                 * below is then one v_bfi_b32 whose only scalar operand is d/2 */
-                uint32_t magn = 0x7fffffffu;
+        /* jcdctmgr.c's sign(v) x floor((|v| + d/2) / d) on the pairs the DCT left:
+         * a = v + copysign(d/2, v); a x rcp, with rcp the float at or just above
+         * 1/d, lies at or above a/d and below the next integer (|a| < 2^18), so
+         * truncating it is the division; two coefficients share the add and the
+         * multiply */
+        const JPEG_CONST jf8 *th = (const JPEG_CONST jf8 *)(uintptr_t)(pass == 0 ? job.qthr_y : job.qthr_c);
+        const JPEG_CONST jf8 *hf = (const JPEG_CONST jf8 *)(uintptr_t)(pass == 0 ? job.qhalf_y : job.qhalf_c);
+        const JPEG_CONST jf8 *rc = (const JPEG_CONST jf8 *)(uintptr_t)(pass == 0 ? job.rcp_y : job.rcp_c);
+        if (mine) {
+            /* everything but the sign bit, in a vector register: the sign transfer
+             * below is then one v_bfi_b32 whose only scalar operand is d/2 */
+            uint32_t magn = 0x7fffffffu;
 #ifndef SPICE_WAVE_SIM
-                asm volatile("" : "+v"(magn));
+            asm volatile("" : "+v"(magn));
 #endif
-                /* The quotients go straight to the block's place in LDS, 16 bits each at
-                 * its zigzag position, as they are made: none of them stays in a
-                 * register waiting for its neighbour in zigzag order. */
-                constexpr int izz[64] = {JIZZ_LIST};
-                uint16_t *dst16 = (uint16_t *)(coef + ((slot > 0 ? slot - 1 : JG_MCUS) * 6 + bidx) * JCOEF_STRIDE);
+            /* The quotients go straight to the block's place in LDS, 16 bits each at
+             * its zigzag position, as they are made: none of them stays in a
+             * register waiting for its neighbour in zigzag order. */
+            constexpr int izz[64] = {JIZZ_LIST};
+            uint16_t *dst16 = (uint16_t *)(coef + ((slot > 0 ? slot - 1 : JG_MCUS) * 6 + bidx) * JCOEF_STRIDE);
 #pragma unroll
-                for (int g = 0; g < 8; g++) {
-                    /* a row of eight coefficients: its constants in three scalar loads */
-                    const jf8 th8 = th[g], hf8 = hf[g], rc8 = rc[g];
+            for (int g = 0; g < 8; g++) {
+                /* a row of eight coefficients: its constants in three scalar loads */
+                const jf8 th8 = th[g], hf8 = hf[g], rc8 = rc[g];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const int j = g * 4 + u;
-                        const jf2 t = pf[j];
-                        const uint64_t stay0 = __ballot(__builtin_fabsf(t[0]) >= th8[2 * u]);
-                        const uint64_t stay1 = __ballot(__builtin_fabsf(t[1]) >= th8[2 * u + 1]);
-                        if (j > 0 && (stay0 | stay1) == 0) {
-                            dst16[izz[2 * j]] = 0;
-                            dst16[izz[2 * j + 1]] = 0;
-                        } else {
-                            /* sign of t over d/2: t ^ ((h ^ t) & magn), one v_bfi_b32 */
-                            const uint32_t b0 = jpeg_fbits(t[0]), b1 = jpeg_fbits(t[1]);
-                            const uint32_t s0 = b0 ^ ((jpeg_fbits(hf8[2 * u]) ^ b0) & magn);
-                            const uint32_t s1 = b1 ^ ((jpeg_fbits(hf8[2 * u + 1]) ^ b1) & magn);
-                            const jf2 a = t + jpeg_f2(jpeg_bitsf(s0), jpeg_bitsf(s1));
-                            const jf2 q = a * jpeg_f2(rc8[2 * u], rc8[2 * u + 1]);
-                            const int q0 = (int)q[0], q1 = (int)q[1];
-                            dst16[izz[2 * j]] = (uint16_t)q0;
-                            dst16[izz[2 * j + 1]] = (uint16_t)q1;
-                            if (j == 0) {
-                                c[0] = q0;
-                            }
+                for (int u = 0; u < 4; u++) {
+                    const int j = g * 4 + u;
+                    const jf2 t = pf[j];
+                    const uint64_t stay0 = __ballot(__builtin_fabsf(t[0]) >= th8[2 * u]);
+                    const uint64_t stay1 = __ballot(__builtin_fabsf(t[1]) >= th8[2 * u + 1]);
+                    if (j > 0 && (stay0 | stay1) == 0) {
+                        dst16[izz[2 * j]] = 0;
+                        dst16[izz[2 * j + 1]] = 0;
+                    } else {
+                        /* sign of t over d/2: t ^ ((h ^ t) & magn), one v_bfi_b32 */
+                        const uint32_t b0 = jpeg_fbits(t[0]), b1 = jpeg_fbits(t[1]);
+                        const uint32_t s0 = b0 ^ ((jpeg_fbits(hf8[2 * u]) ^ b0) & magn);
+                        const uint32_t s1 = b1 ^ ((jpeg_fbits(hf8[2 * u + 1]) ^ b1) & magn);
+                        const jf2 a = t + jpeg_f2(jpeg_bitsf(s0), jpeg_bitsf(s1));
+                        const jf2 q = a * jpeg_f2(rc8[2 * u], rc8[2 * u + 1]);
+                        const int q0 = (int)q[0], q1 = (int)q[1];
+                        dst16[izz[2 * j]] = (uint16_t)q0;
+                        dst16[izz[2 * j + 1]] = (uint16_t)q1;
+                        if (j == 0) {
+                            c[0] = q0;
                         }
                     }
                 }
-            } else {
-                for (int j = 0; j < 64; j++) {
-                    (void)__ballot(false);
-                }
             }
         } else {
-            const JPEG_CONST int *dv = (const JPEG_CONST int *)(uintptr_t)(pass == 0 ? job.div_y : job.div_c);
-            const JPEG_CONST float *rc = (const JPEG_CONST float *)(uintptr_t)(pass == 0 ? job.rcp_y : job.rcp_c);
-            if (mine) {
-#pragma unroll
-                for (int i = 0; i < 64; i++) {
-                    const int d = dv[i];
-                    const int thr = d - (d >> 1);
-                    const bool stays = (unsigned)(c[i] + thr - 1) >= (unsigned)(2 * thr - 1);
-                    if (i > 0 && __ballot(stays) == 0) {
-                        c[i] = 0;
-                    } else {
-                        c[i] = jpeg_quant(c[i], d, rc[i]);
-                    }
-                }
-            } else {
-                for (int i = 1; i < 64; i++) {
-                    (void)__ballot(false);
-                }
+            for (int j = 0; j < 64; j++) {
+                (void)__ballot(false);
             }
         }
     }
     if (have && real) {
         dcq[slot * 6 + bidx] = c[0];
-    } else if (!IFAST) {
-#pragma unroll
-        for (int i = 0; i < 64; i++) {
-            c[i] = 0;
-        }
     }
-    if (IFAST) {
-        /* a dummy block is all zeros (its DC comes out of dcq below) */
-        if (have && !real && slot > 0) {
-            uint32_t *dst = coef + ((slot - 1) * 6 + bidx) * JCOEF_STRIDE;
-#pragma unroll
-            for (int j = 0; j < 32; j++) {
-                dst[j] = 0;
-            }
-        }
-    } else if (have && slot > 0) {
-        /* zigzag order, two coefficients per word; a dummy block is all zeros
-         * (its DC comes out of dcq below) */
-        constexpr int zz[64] = {JZZ_LIST};
+    /* a dummy block is all zeros (its DC comes out of dcq below) */
+    if (have && !real && slot > 0) {
         uint32_t *dst = coef + ((slot - 1) * 6 + bidx) * JCOEF_STRIDE;
 #pragma unroll
         for (int j = 0; j < 32; j++) {
-            dst[j] = ((uint32_t)c[zz[2 * j]] & 0xffffu) | ((uint32_t)c[zz[2 * j + 1]] << 16);
+            dst[j] = 0;
         }
     }
     __syncthreads();

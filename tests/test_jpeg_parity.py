@@ -117,18 +117,44 @@ def test_sim_negative_stride_and_capacity(sim, oracle):
     run_capacity_error(sim)
 
 
-def test_quantiser_reciprocal_is_one_sided():
-    """the arithmetic claim behind jpeg_quant (jpeg_kernels.hip) and the table jpeg_host.cpp fills:
-    with 1/d rounded down by a part in 2^20, trunc(float(a) * rcp) is floor(a / d) or one less,
-    for every dividend below 2^17 and every divisor a quantisation table can hold"""
-    a = np.arange(0, 1 << 17, dtype=np.uint32)
+def test_quantiser_in_single_precision_is_exact():
+    """the arithmetic claim behind the strip kernel's quantiser (jpeg_kernels.hip) and the tables
+    jpeg_host.cpp fills: with rcp the single-precision number at or just above 1/d,
+    trunc(float32(a) * rcp) = a // d for every dividend a = |v| + d/2 below 2^17 + d and every
+    divisor a quantisation table can hold (jcdctmgr.c divides |v| + d/2 by d and restores the sign;
+    the kernel does the same on v + copysign(d/2, v) and truncates towards zero)"""
+    a = np.arange(0, (1 << 17) + 4200, dtype=np.uint32)
     af = a.astype(np.float32)
     for d in range(1, 4200):
-        rcp = np.float32((1.0 / d) * (1.0 - 1.0 / 1048576.0))
-        q = (af * rcp).astype(np.uint32)
-        rem = a.astype(np.int64) - q.astype(np.int64) * d
-        assert (rem >= 0).all() and (rem < 2 * d).all(), d
-        assert np.array_equal(q + (rem >= d), a // d), d
+        rcp = np.float32(1.0 / d)
+        if float(rcp) * d < 1.0:
+            rcp = np.nextafter(rcp, np.float32(2.0))
+        assert float(rcp) * d >= 1.0 and float(np.nextafter(rcp, np.float32(0.0))) * d < 1.0 or float(rcp) * d == 1.0
+        q = (af * rcp).astype(np.int64)          # float32 product, rounded to nearest, then truncated
+        assert np.array_equal(q, a.astype(np.int64) // d), d
+        qn = ((-af) * rcp).astype(np.int64)      # the negative side truncates towards zero as well
+        assert np.array_equal(qn, -(a.astype(np.int64) // d)), d
+
+
+def test_ifast_dct_in_single_precision_is_exact():
+    """the claim behind jpeg_fdct_ifast_f2: every product of jfdctfst.c's passes stays below 2^24 in
+    magnitude for 8-bit samples, so floor(float32(x) * float32(c / 256)) is x * c >> 8 (worst-case
+    magnitudes of the operands of each multiplication, pass by pass)"""
+    m = 255  # unsigned samples: the kernel removes the level shift from the DC term afterwards
+    for _ in range(2):
+        t = 2 * m                       # t0..t7 of a pass
+        t1x = 2 * t                     # t10..t13 and t10..t12 of the odd part
+        prods = [(2 * t1x, 181), (2 * t1x, 98), (t1x, 139), (t1x, 334), (t1x, 181)]
+        for x, c in prods:
+            assert x * c < 1 << 24, (x, c)
+        z = max((x * c) >> 8 for x, c in prods)
+        m = max(4 * t, t + 3 * z)       # a bound on what the pass hands to the next (d0 = sum of all eight; odd outputs)
+    xs = np.arange(-(1 << 16), 1 << 16, dtype=np.int64)
+    for c in (98, 139, 181, 334):
+        want = (xs * c) >> 8
+        got = np.floor(xs.astype(np.float32) * np.float32(c / 256.0)).astype(np.int64)
+        keep = np.abs(xs * c) < (1 << 24)
+        assert np.array_equal(want[keep], got[keep]), c
 
 
 # ------------------------------------------------------------------------ GPU
