@@ -957,9 +957,16 @@ __device__ __forceinline__ void jpeg_strip_body(const JpegDevJob &job, const uin
             int run = 0;
             if (on) {
                 int kprev = 0; /* zigzag index of the last coefficient coded */
+                /* the block's 32 words are asked for at once: read one by one, inside the
+                 * tests below, each would cost the walk a whole LDS round trip */
+                uint32_t xw[32];
 #pragma unroll
                 for (int w = 0; w < 32; w++) {
-                    const uint32_t x = cw[w];
+                    xw[w] = cw[w];
+                }
+#pragma unroll
+                for (int w = 0; w < 32; w++) {
+                    const uint32_t x = xw[w];
                     if (w > 0 && x == 0) {
                         continue;
                     }
