@@ -37,7 +37,6 @@ struct JpegDevJob {
     int32_t yb_w, yb_h;                 /* real luma blocks per row / column */
     int32_t div_y[64], div_c[64];       /* jcdctmgr divisors, natural order */
     float rcp_y[64], rcp_c[64];         /* the single-precision number at or just above 1 / divisor */
-    float qthr_y[64], qthr_c[64];       /* divisor - divisor / 2: the least magnitude that does not round to zero */
     float qhalf_y[64], qhalf_c[64];     /* divisor / 2 (integer division) */
     uint8_t *out;
     uint32_t out_cap;

@@ -226,8 +226,6 @@ bool fill_job(JpegDevJob *j, const void *pixels, int format, int width, int heig
          * reciprocal must not lie below 1/d */
         j->rcp_y[i] = recip_not_below(j->div_y[i]);
         j->rcp_c[i] = recip_not_below(j->div_c[i]);
-        j->qthr_y[i] = (float)(j->div_y[i] - (j->div_y[i] >> 1));
-        j->qthr_c[i] = (float)(j->div_c[i] - (j->div_c[i] >> 1));
         j->qhalf_y[i] = (float)(j->div_y[i] >> 1);
         j->qhalf_c[i] = (float)(j->div_c[i] >> 1);
     }

@@ -821,19 +821,13 @@ __device__ __forceinline__ void jpeg_strip_body(const JpegDevJob &job, const uin
         if (__ballot(mine) == 0) {
             continue;
         }
-        /* A coefficient below its threshold (|v| + d/2 < d) rounds to zero; away from
-         * the low frequencies that holds for every block of the wavefront more often
-         * than not, and the division is skipped for all of them at once.  Lanes of the
-         * other table answer the votes with a constant "no": the compiler drops that
-         * loop (an inactive lane's vote reads as zero anyway), while the CPU wave
-         * simulator, where a vote waits for every lane of the wavefront, needs the
-         * calls to pair up. */
         /* jcdctmgr.c's sign(v) x floor((|v| + d/2) / d) on the pairs the DCT left:
          * a = v + copysign(d/2, v); a x rcp, with rcp the float at or just above
          * 1/d, lies at or above a/d and below the next integer (|a| < 2^18), so
          * truncating it is the division; two coefficients share the add and the
-         * multiply */
-        const JPEG_CONST jf8 *th = (const JPEG_CONST jf8 *)(uintptr_t)(pass == 0 ? job.qthr_y : job.qthr_c);
+         * multiply.  (Skipping the division where a whole wavefront's coefficients
+         * round to zero, as the integer quantiser did, no longer pays: the votes cost
+         * what the six instructions of a pair do.) */
         const JPEG_CONST jf8 *hf = (const JPEG_CONST jf8 *)(uintptr_t)(pass == 0 ? job.qhalf_y : job.qhalf_c);
         const JPEG_CONST jf8 *rc = (const JPEG_CONST jf8 *)(uintptr_t)(pass == 0 ? job.rcp_y : job.rcp_c);
         if (mine) {
@@ -850,36 +844,25 @@ __device__ __forceinline__ void jpeg_strip_body(const JpegDevJob &job, const uin
             uint16_t *dst16 = (uint16_t *)(coef + ((slot > 0 ? slot - 1 : JG_MCUS) * 6 + bidx) * JCOEF_STRIDE);
 #pragma unroll
             for (int g = 0; g < 8; g++) {
-                /* a row of eight coefficients: its constants in three scalar loads */
-                const jf8 th8 = th[g], hf8 = hf[g], rc8 = rc[g];
+                /* a row of eight coefficients: its constants in two scalar loads */
+                const jf8 hf8 = hf[g], rc8 = rc[g];
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const int j = g * 4 + u;
                     const jf2 t = pf[j];
-                    const uint64_t stay0 = __ballot(__builtin_fabsf(t[0]) >= th8[2 * u]);
-                    const uint64_t stay1 = __ballot(__builtin_fabsf(t[1]) >= th8[2 * u + 1]);
-                    if (j > 0 && (stay0 | stay1) == 0) {
-                        dst16[izz[2 * j]] = 0;
-                        dst16[izz[2 * j + 1]] = 0;
-                    } else {
-                        /* sign of t over d/2: t ^ ((h ^ t) & magn), one v_bfi_b32 */
-                        const uint32_t b0 = jpeg_fbits(t[0]), b1 = jpeg_fbits(t[1]);
-                        const uint32_t s0 = b0 ^ ((jpeg_fbits(hf8[2 * u]) ^ b0) & magn);
-                        const uint32_t s1 = b1 ^ ((jpeg_fbits(hf8[2 * u + 1]) ^ b1) & magn);
-                        const jf2 a = t + jpeg_f2(jpeg_bitsf(s0), jpeg_bitsf(s1));
-                        const jf2 q = a * jpeg_f2(rc8[2 * u], rc8[2 * u + 1]);
-                        const int q0 = (int)q[0], q1 = (int)q[1];
-                        dst16[izz[2 * j]] = (uint16_t)q0;
-                        dst16[izz[2 * j + 1]] = (uint16_t)q1;
-                        if (j == 0) {
-                            c[0] = q0;
-                        }
+                    /* sign of t over d/2: t ^ ((h ^ t) & magn), one v_bfi_b32 */
+                    const uint32_t b0 = jpeg_fbits(t[0]), b1 = jpeg_fbits(t[1]);
+                    const uint32_t s0 = b0 ^ ((jpeg_fbits(hf8[2 * u]) ^ b0) & magn);
+                    const uint32_t s1 = b1 ^ ((jpeg_fbits(hf8[2 * u + 1]) ^ b1) & magn);
+                    const jf2 a = t + jpeg_f2(jpeg_bitsf(s0), jpeg_bitsf(s1));
+                    const jf2 q = a * jpeg_f2(rc8[2 * u], rc8[2 * u + 1]);
+                    const int q0 = (int)q[0], q1 = (int)q[1];
+                    dst16[izz[2 * j]] = (uint16_t)q0;
+                    dst16[izz[2 * j + 1]] = (uint16_t)q1;
+                    if (j == 0) {
+                        c[0] = q0;
                     }
                 }
-            }
-        } else {
-            for (int j = 0; j < 64; j++) {
-                (void)__ballot(false);
             }
         }
     }
