@@ -361,6 +361,16 @@ typedef struct SpiceGpuJpegJob {
 
 size_t spice_gpu_jpeg_out_bound(int width, int height);
 int spice_gpu_jpeg_encode_batch(SpiceGpuJpegJob *jobs, int njobs);
+/* The same in two halves.  A thread may have TWO batches in flight: submit, submit,
+ * finish, submit, finish ...  Each runs on a stream of its own with its own scratch;
+ * the second batch's strip kernel starts when the first one's has ended, so what
+ * overlaps is one batch's short bit-stream kernels, copies and host work with the
+ * other's strip kernel (a video server codes frame k+1 of its streams while the bytes
+ * of frame k are still being put together).  finish completes the OLDEST batch and
+ * takes that batch's job array; the two batches must not share output buffers.  A
+ * third submit, a finish whose job count is not the oldest batch's, and
+ * spice_gpu_jpeg_encode_batch while batches are in flight are refused; another
+ * thread's submit waits until the last batch in flight has been finished. */
 int spice_gpu_jpeg_submit(SpiceGpuJpegJob *jobs, int njobs);
 int spice_gpu_jpeg_finish(SpiceGpuJpegJob *jobs, int njobs);
 

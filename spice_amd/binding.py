@@ -790,8 +790,13 @@ class JpegBatchPlan:
     video streams): geometry, quality and output buffers stay, only the frames'
     device pointers change.  Saves rebuilding the job array per call."""
 
-    def __init__(self, gpu, items):
+    def __init__(self, gpu, items, alt_outs=None):
+        """alt_outs: a second set of output buffers (device pointers, one per job), needed
+        to keep two batches in flight (submit / finish): the batches alternate between the
+        items' buffers and these, so one batch's streams are never written while the
+        previous batch's are still being produced."""
         self.gpu, self.n = gpu, len(items)
+        self.alt_outs = alt_outs
         self.jobs = (SpiceGpuJpegJob * self.n)()
         for j, it in enumerate(items):
             job = self.jobs[j]
@@ -812,6 +817,55 @@ class JpegBatchPlan:
         if self.gpu.L.spice_gpu_jpeg_encode_batch(self.jobs, self.n) != 0:
             raise SpiceGpuError("jpeg batch: " + self.gpu.last_error())
         return self._sizes.copy()
+
+    # Two batches in flight (spice_gpu_jpeg_submit twice before the first finish): the
+    # plan keeps a second copy of its job array with the second set of output buffers, so
+    # that neither the array nor the streams of the batch in flight are touched while the
+    # next one runs.  A caller that pipelines reads the streams of batch k (finish returns
+    # which set they are in: `last_outs`) before it submits batch k+2.
+    def submit(self, pixels=None):
+        """Starts the next batch; at most two may be in flight."""
+        if not hasattr(self, "_ring"):
+            if self.alt_outs is None or len(self.alt_outs) != self.n:
+                raise SpiceGpuError("jpeg plan: submit/finish need alt_outs, a second set of output buffers")
+            second = (SpiceGpuJpegJob * self.n)()
+            C.memmove(second, self.jobs, C.sizeof(self.jobs))
+            for j in range(self.n):
+                second[j].out = self.alt_outs[j]
+            self._ring = [self.jobs, second]
+            self._ring_pixels = [self._pixels,
+                                 np.ndarray((self.n,), dtype=np.uint64, buffer=second,
+                                            offset=SpiceGpuJpegJob.pixels.offset,
+                                            strides=(C.sizeof(SpiceGpuJpegJob),))]
+            self._ring_sizes = [self._sizes,
+                                np.ndarray((self.n,), dtype=np.int32, buffer=second,
+                                           offset=SpiceGpuJpegJob.out_size.offset,
+                                           strides=(C.sizeof(SpiceGpuJpegJob),))]
+            self._head, self._inflight = 0, 0
+        if self._inflight == 2:
+            raise SpiceGpuError("jpeg plan: two batches are in flight")
+        slot = (self._head + self._inflight) & 1
+        if pixels is not None:
+            self._ring_pixels[slot][:] = pixels
+        if self.gpu.L.spice_gpu_jpeg_submit(self._ring[slot], self.n) != 0:
+            raise SpiceGpuError("jpeg batch: " + self.gpu.last_error())
+        self._inflight += 1
+
+    def finish(self):
+        """Completes the oldest batch in flight and returns its JFIF sizes."""
+        if not getattr(self, "_inflight", 0):
+            raise SpiceGpuError("jpeg plan: nothing in flight")
+        slot = self._head
+        rc = self.gpu.L.spice_gpu_jpeg_finish(self._ring[slot], self.n)
+        self._head ^= 1
+        self._inflight -= 1
+        if rc != 0:
+            raise SpiceGpuError("jpeg batch: " + self.gpu.last_error())
+        self.last_outs = [int(self._ring[slot][j].out) for j in range(self.n)] if slot else None
+        return self._ring_sizes[slot].copy()
+
+    def in_flight(self):
+        return getattr(self, "_inflight", 0)
 
 
 def graduality_batch(gpu, items):

@@ -21,7 +21,8 @@
 using namespace spicegpu;
 
 void jpeg_launch(const JpegDevJob *jobs, int njobs, int max_groups, bool any_islow, bool any_ifast,
-                 const uint32_t *huff, hipStream_t stream, bool timed = true);
+                 const uint32_t *huff, hipStream_t stream, bool timed, hipEvent_t strips_after,
+                 hipEvent_t strips_done);
 void jpeg_huff_words(uint32_t *h);
 
 namespace {
@@ -312,8 +313,22 @@ struct JpegFlight {
     uint64_t t0 = 0;
     uint64_t raw_bytes = 0;
     int stat_codec = SPICE_GPU_STAT_MJPEG;
+    hipEvent_t strips_done = nullptr; /* recorded behind this flight's strip kernels */
 };
-JpegFlight g_jf;
+/* Two batches may be in flight, the second submitted while the first still runs: each has
+ * its own stream, job upload area and scratch, so the kernels of one overlap the host's
+ * work for, and the short bit-stream kernels of, the other.  g_jf is slot 0, which the
+ * synchronous entry points use as well.  All of it belongs to the thread that holds the
+ * device gate. */
+JpegFlight g_jfs[2];
+JpegFlight &g_jf = g_jfs[0];
+int g_jf_head = 0;   /* the older active flight */
+int g_jf_active = 0; /* 0..2 */
+
+hipStream_t flight_stream(const JpegFlight &f)
+{
+    return &f == &g_jfs[1] ? side_stream() : stream();
+}
 
 bool ensure_huff(JpegFlight &f)
 {
@@ -377,12 +392,19 @@ bool submit_locked(JpegFlight &f, std::vector<JpegDevJob> &jobs)
         j.result = (int32_t *)(f.staging.dev + jobs_bytes) + k;
         hj[k] = j;
     }
-    hipStream_t s = stream();
+    hipStream_t s = flight_stream(f);
     if (!check(hipMemcpyAsync(f.staging.dev, f.staging.host, jobs_bytes, hipMemcpyHostToDevice, s),
                "upload jpeg jobs")) {
         return false;
     }
-    jpeg_launch((const JpegDevJob *)f.staging.dev, n, max_groups, any_islow, any_ifast, f.d_huff, s);
+    if (!f.strips_done &&
+        !check(hipEventCreate(&f.strips_done), "hipEventCreate")) {
+        return false;
+    }
+    /* the other slot's strip kernels first, if it has a batch in flight */
+    JpegFlight &other = g_jfs[&f == &g_jfs[0] ? 1 : 0];
+    jpeg_launch((const JpegDevJob *)f.staging.dev, n, max_groups, any_islow, any_ifast, f.d_huff, s, true,
+                other.active ? other.strips_done : nullptr, f.strips_done);
     if (!check(hipGetLastError(), "jpeg launch")) {
         return false;
     }
@@ -770,7 +792,6 @@ int spice_gpu_jpeg_submit(SpiceGpuJpegJob *jobs, int njobs)
         set_error("jpeg batch: no jobs");
         return -1;
     }
-    JpegFlight &f = g_jf;
     std::vector<JpegDevJob> dj((size_t)njobs);
     uint64_t raw_bytes = 0;
     for (int k = 0; k < njobs; k++) {
@@ -783,30 +804,47 @@ int spice_gpu_jpeg_submit(SpiceGpuJpegJob *jobs, int njobs)
         }
         raw_bytes += (uint64_t)j.width * (uint64_t)j.height * (uint64_t)format_bpp(j.format);
     }
-    /* the gate stays taken until spice_gpu_jpeg_finish; a second submit from this
-     * thread is refused, one from another thread waits for the finish */
-    if (!device_gate().acquire("jpeg batch")) {
+    /* The gate stays taken from a thread's first submit until its last finish.  The
+     * thread that holds it for a JPEG batch may submit one more; a third submit, or a
+     * submit while it holds the gate for something else, is refused; a submit from
+     * another thread waits for the finish. */
+    const bool mine = device_gate().held_by_caller();
+    if (mine && (g_jf_active == 0 || g_jf_active == 2)) {
+        set_error(g_jf_active ? "jpeg batch: two batches are in flight already (finish one first)"
+                              : "jpeg batch: this thread has another batch in flight");
         return -1;
     }
+    if (!mine && !device_gate().acquire("jpeg batch")) {
+        return -1;
+    }
+    JpegFlight &f = g_jfs[(g_jf_head + g_jf_active) & 1];
     f.raw_bytes = raw_bytes;
     f.t0 = now_ns();
     if (!submit_locked(f, dj)) {
-        hipStreamSynchronize(stream());
-        device_gate().release();
+        hipStreamSynchronize(flight_stream(f));
+        if (g_jf_active == 0) {
+            device_gate().release();
+        }
         return -1;
     }
     f.active = true;
+    g_jf_active++;
     return 0;
 }
 
+/* Completes the OLDEST batch in flight: jobs / njobs are that batch's. */
 int spice_gpu_jpeg_finish(SpiceGpuJpegJob *jobs, int njobs)
 {
-    JpegFlight &f = g_jf;
-    if (!f.active || njobs != f.njobs) {
+    if (!device_gate().held_by_caller() || g_jf_active == 0) {
         set_error("jpeg batch: finish without a matching submit");
         return -1;
     }
-    bool ok = check(hipStreamSynchronize(stream()), "jpeg batch sync");
+    JpegFlight &f = g_jfs[g_jf_head];
+    if (!f.active || njobs != f.njobs) {
+        set_error("jpeg batch: finish does not match the oldest batch in flight (%d jobs, not %d)", f.njobs, njobs);
+        return -1;
+    }
+    bool ok = check(hipStreamSynchronize(flight_stream(f)), "jpeg batch sync");
     const int32_t *res = (const int32_t *)(f.staging.host + f.results_off);
     int rc = ok ? 0 : -1;
     for (int k = 0; k < njobs; k++) {
@@ -826,12 +864,20 @@ int spice_gpu_jpeg_finish(SpiceGpuJpegJob *jobs, int njobs)
         }
     }
     f.active = false;
-    device_gate().release();
+    g_jf_head ^= 1;
+    if (--g_jf_active == 0) {
+        g_jf_head = 0;
+        device_gate().release();
+    }
     return rc;
 }
 
 int spice_gpu_jpeg_encode_batch(SpiceGpuJpegJob *jobs, int njobs)
 {
+    if (device_gate().held_by_caller()) {
+        set_error("jpeg batch: this thread has a batch in flight (finish it first)");
+        return -1;
+    }
     if (spice_gpu_jpeg_submit(jobs, njobs) != 0) {
         return -1;
     }

@@ -141,6 +141,12 @@ void DeviceGate::release()
     g_gate_cv.notify_one();
 }
 
+bool DeviceGate::held_by_caller()
+{
+    std::lock_guard<std::mutex> lk(g_gate_mutex);
+    return g_gate_busy && g_gate_owner == std::this_thread::get_id();
+}
+
 DeviceGate &device_gate()
 {
     return g_gate;

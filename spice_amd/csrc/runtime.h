@@ -38,6 +38,8 @@ public:
     /* false (with the error text set) when the calling thread already holds the gate */
     bool acquire(const char *who);
     void release();
+    /* the calling thread holds the gate right now */
+    bool held_by_caller();
 };
 DeviceGate &device_gate();
 

@@ -232,8 +232,67 @@ def run_batch_plan(dev, oracle):
         dev.free(p)
 
 
+def run_two_in_flight(dev, oracle, w=160, h=96, rounds=6):
+    """Two batches in flight (submit, submit, finish, submit, finish ...): every batch's streams
+    equal libjpeg's, whichever of the two buffer sets they land in; a third submit, a finish of
+    the wrong batch and a synchronous batch in between are refused without breaking the pipeline."""
+    kinds = ("desktop", "noise", "smooth")
+    px = [frames.golden_image(w, h, kinds[s % 3], 11 + s).reshape(h, w * 4) for s in range(4)]
+    want = {(k, q, d): oracle.jpeg_encode(px[k], w, h, w * 4, 8, q, d)
+            for k in range(4) for (q, d) in ((70, B.DCT_IFAST), (85, B.DCT_ISLOW))}
+    d_px = [dev.to_device(p) for p in px]
+    cap = dev.L.spice_gpu_jpeg_out_bound(w, h)
+    n = 3
+    d_out = [dev.malloc(cap) for _ in range(n)]
+    d_out2 = [dev.malloc(cap) for _ in range(n)]
+    params = [(70, B.DCT_IFAST), (85, B.DCT_ISLOW), (70, B.DCT_IFAST)]
+    plan = B.JpegBatchPlan(dev, [dict(pixels=d_px[0], format=B.BITMAP_FMT_32BIT, width=w, height=h, stride=w * 4,
+                                      quality=params[j][0], dct=params[j][1], out=d_out[j], out_capacity=cap)
+                                 for j in range(n)], alt_outs=d_out2)
+    orders = [[(r + j) % 4 for j in range(n)] for r in range(rounds)]
+    pending = []
+
+    def check_oldest():
+        sizes = plan.finish()
+        order = pending.pop(0)
+        outs = plan.last_outs or d_out
+        for j, k in enumerate(order):
+            assert_same_stream(want[(k,) + params[j]], dev.download(outs[j], int(sizes[j])), "pipelined job %d" % j)
+
+    for r, order in enumerate(orders):
+        if plan.in_flight() == 2:
+            check_oldest()
+        plan.submit(np.array([d_px[k] for k in order], dtype=np.uint64))
+        pending.append(order)
+        if r == 1:
+            assert plan.in_flight() == 2
+            with pytest.raises(B.SpiceGpuError):        # a third batch
+                plan.submit(np.array([d_px[k] for k in order], dtype=np.uint64))
+            with pytest.raises(B.SpiceGpuError):        # a synchronous batch while the thread has flights
+                plan.run()
+            wrong = (B.SpiceGpuJpegJob * (n + 1))()
+            assert dev.L.spice_gpu_jpeg_finish(wrong, n + 1) != 0   # not the oldest batch's job count
+    while plan.in_flight():
+        check_oldest()
+    # the synchronous way still works afterwards (the gate was released)
+    sizes = plan.run(np.array([d_px[k] for k in (3, 2, 1)], dtype=np.uint64))
+    for j, k in enumerate((3, 2, 1)):
+        assert_same_stream(want[(k,) + params[j]], dev.download(d_out[j], int(sizes[j])), "after the pipeline")
+    for p in d_px + d_out + d_out2:
+        dev.free(p)
+
+
 def test_sim_batch_plan(sim, oracle):
     run_batch_plan(sim, oracle)
+
+
+def test_sim_two_batches_in_flight(sim, oracle):
+    run_two_in_flight(sim, oracle)
+
+
+@pytest.mark.gpu
+def test_gpu_two_batches_in_flight(gpu, oracle):
+    run_two_in_flight(gpu, oracle, 1280, 720, rounds=9)
 
 
 @pytest.mark.gpu
