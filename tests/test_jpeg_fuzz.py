@@ -126,3 +126,47 @@ def test_sim_density_sweep(sim, oracle):
 @pytest.mark.gpu
 def test_gpu_density_sweep(gpu, oracle):
     run_density_sweep(gpu, oracle, range(2, 101, 2))
+
+
+def extreme_frames(w, h):
+    """the inputs that drive the DCT's operands and the quantiser's dividends to their bounds"""
+    y, x = np.mgrid[0:h, 0:w]
+    out = []
+    for name, v in (("black", np.zeros((h, w), np.uint8)), ("white", np.full((h, w), 255, np.uint8)),
+                    ("checker1", ((x + y) & 1) * 255), ("columns", (x & 1) * 255), ("rows", (y & 1) * 255),
+                    ("checker8", (((x >> 3) + (y >> 3)) & 1) * 255), ("halves", (x < w // 2) * 255),
+                    ("checker4", (((x >> 2) + (y >> 2)) & 1) * 255)):
+        im = np.zeros((h, w, 4), np.uint8)
+        im[..., :3] = np.asarray(v, np.uint8)[..., None]
+        out.append((name, im))
+    im = np.zeros((h, w, 4), np.uint8)            # saturated primaries against each other: chroma at its bounds
+    im[..., 0] = ((x >> 1) & 1) * 255
+    im[..., 1] = ((y >> 1) & 1) * 255
+    im[..., 2] = (((x + y) >> 2) & 1) * 255
+    out.append(("primaries", im))
+    return out
+
+
+def run_extremes(dev, oracle, w=48, h=32):
+    """The single-precision DCT and quantiser at the ends of their ranges (full-swing
+    patterns at every spatial frequency, quality 1 = divisors at their largest, quality 100 =
+    divisor 1 x scale), both DCTs: byte-identical to the integer restatement of libjpeg."""
+    items, wants, names = [], [], []
+    for name, im in extreme_frames(w, h):
+        px = im.reshape(h, w * 4)
+        for q in (1, 2, 50, 99, 100):
+            for dct in (0, 1):
+                items.append((px, w, h, B.BITMAP_FMT_32BIT, q, dct, 1))
+                wants.append(oracle.jpeg_encode(px, w, h, w * 4, 8, q, dct))
+                names.append("%s q %d dct %d" % (name, q, dct))
+    for name, want, got in zip(names, wants, batch_encode(dev, items)):
+        assert_same_stream(want, got, name)
+
+
+def test_sim_extremes(sim, oracle):
+    run_extremes(sim, oracle)
+
+
+@pytest.mark.gpu
+def test_gpu_extremes(gpu, oracle):
+    run_extremes(gpu, oracle, 208, 112)

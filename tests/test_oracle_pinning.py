@@ -63,6 +63,23 @@ def test_jpeg_oracle_matches_live_libjpeg(oracle):
                 assert len(want) == len(got) and (want == got).all(), (w, h, q, dct)
 
 
+def test_jpeg_oracle_matches_live_libjpeg_at_the_extremes(oracle):
+    """full-swing patterns at every spatial frequency, qualities 1..100: where the DCT's operands
+    and the quantiser's dividends reach their bounds (the kernels' single-precision arithmetic is
+    checked against the restatement on exactly these frames, tests/test_jpeg_fuzz.py)"""
+    O = oracle
+    if O.ref() is None:
+        pytest.skip("oracle/_ref/libjpegref.so not built on this machine")
+    from test_jpeg_fuzz import extreme_frames
+    for name, im in extreme_frames(48, 32):
+        a = im.reshape(32, 48 * 4)
+        for q in (1, 2, 50, 99, 100):
+            for dct in (O.DCT_ISLOW, O.DCT_IFAST):
+                want = O.ref_jpeg_encode(a, 48, 32, 48 * 4, O.FMT_32BIT, q, dct, 0)
+                got = O.jpeg_encode(a, 48, 32, 48 * 4, O.FMT_32BIT, q, dct)
+                assert len(want) == len(got) and (want == got).all(), (name, q, dct)
+
+
 def test_jpeg_colour_constants_of_v6b_and_ijg9_agree():
     """libjpeg 9 rounds two Cb coefficients differently from v6b / libjpeg-turbo
     (11058/21710 vs 11059/21709); over 8-bit input the results never differ."""
