@@ -155,9 +155,14 @@ __device__ __forceinline__ uint32_t glz_hash3(uint32_t a, uint32_t b, uint32_t c
     return h & GLZ_HASH_MASK;
 }
 
+/* cap = GLZ_NO_CAP, written as that constant: the caller has checked that the whole token
+ * fits, the test folds away and the store is plain (a test per byte is a compare, two
+ * exec-mask instructions and a branch, and a match token has up to nine bytes) */
+#define GLZ_NO_CAP 0xffffffffu
+
 __device__ __forceinline__ void glz_put(GLZ_GLOBAL uint8_t *buf, uint32_t cap, uint32_t pos, uint32_t b)
 {
-    if (pos < cap) {
+    if (cap == GLZ_NO_CAP || pos < cap) {
         buf[pos] = (uint8_t)b;
     }
 }
@@ -836,14 +841,20 @@ __device__ __forceinline__ void glz_window_scan(const GlzDevJob &job, const GlzD
     /* (2) the table's entry: validation and do_match's distance rules
      * (glz_encode_tmpl.c:147-229); its pixels are requested here and compared
      * in (4) */
-    bool gok = false, capped = false;
-    int maxk = 0;
-    uint32_t gidist = 0, gpdist = 0;
+    /* everything but gok is read only where gok says it was set: left unset otherwise, so
+     * that no path spends instructions on zeroing a dozen registers for the others */
+    bool gok = false, capped;
+    int maxk;
+    uint32_t gidist, gpdist;
     uint32_t r[GLZ_K];
-#pragma unroll
+#ifdef SPICE_WAVE_SIM
+    capped = false;
+    maxk = 0;
+    gidist = gpdist = 0;
     for (int k = 0; k < GLZ_K; k++) {
         r[k] = 0;
     }
+#endif
     if (look) {
         /* the stores the previous window's last match left for positions ip-2 and
          * ip-1 are the newest entries of their slots, whatever the probe saw */
@@ -1599,21 +1610,29 @@ __device__ __forceinline__ void glz_window_emit(const GlzDevJob &job, uint32_t s
     uint32_t off = op_in + incl - bytes + (w > 0 ? ws0 : 0u) + (w > 1 ? ws1 : 0u) + (w > 2 ? ws2 : 0u);
 
     EMIT_STAMP(3);
-    /* (4) write */
+    /* (4) write.  A token that does not fit whole is not written at all: the image
+     * then ends in GLZ_DEV_ERR_NO_SPACE (op runs past out_cap) and nobody reads its bytes. */
+    const bool fits = off + bytes <= job.out_cap;
     if (is_lit) {
         if (cs) {
-            glz_put(glz_out(job), job.out_cap, off, closed ? (rem < 32 ? rem : 32) - 1 : GLZ_MAX_COPY - 1);
+            if (fits) {
+                glz_put(glz_out(job), GLZ_NO_CAP, off, closed ? (rem < 32 ? rem : 32) - 1 : GLZ_MAX_COPY - 1);
+            }
             if (!closed && rem <= 32) {
                 sh.last_copy = off; /* the count byte a later window may have to patch */
             }
             off++;
         }
-        glz_put_pixel<MODE>(glz_out(job), job.out_cap, off, sh.tile[p + 1]);
+        if (fits) {
+            glz_put_pixel<MODE>(glz_out(job), GLZ_NO_CAP, off, sh.tile[p + 1]);
+        }
     } else if (is_ms) {
         if (first_run && c0 > 0 && r < 32) {
             glz_put(glz_out(job), job.out_cap, lc_in, r - 1); /* glz_encoder.c:95-108 */
         }
-        glz_write_match(glz_out(job), job.out_cap, off, idist, pdist, elen, 16);
+        if (fits) {
+            glz_write_match(glz_out(job), GLZ_NO_CAP, off, idist, pdist, elen, 16);
+        }
     }
     {
         uint64_t big = __ballot(is_ms && nff > 16);
