@@ -36,6 +36,7 @@
 
 #include "glz_device.h"
 #include "runtime.h"
+#include "wave_ops.h"
 
 #define GLZ_WAVE 64
 #define GLZ_THREADS 256
@@ -1560,32 +1561,27 @@ __device__ __forceinline__ void glz_window_emit(const GlzDevJob &job, uint32_t s
         const uint32_t *ins32 = (const uint32_t *)sh.ins;
         const uint32_t a = sh.infoA[p], b = sh.infoB[p];
         const uint32_t n1 = (a >> GLZ_A_P1_SHIFT) & 255u, n2 = b & 255u;
-        uint32_t tok;
-        if ((sh.slow[p >> 6] >> lane) & 1) {
-            tok = sh.tok[p];
-        } else if (a & GLZ_A_RLE) {
-            tok = (b & 0x1ffu) | (GLZ_SEL_RUN << 29); /* the run's length, as the scan left it */
-        } else if ((a & GLZ_A_P1V) && ((ins32[n1 >> 5] >> (n1 & 31u)) & 1u)) {
-            /* the same choice wavefront 0 made, now that every store is known */
-            tok = ((a >> GLZ_A_LEN1_SHIFT) & 31u) | (GLZ_SEL_P1 << 29);
-        } else if ((a & GLZ_A_P2V) && ((ins32[n2 >> 5] >> (n2 & 31u)) & 1u)) {
-            tok = ((b >> GLZ_B_LEN2_SHIFT) & 31u) | (GLZ_SEL_P2 << 29);
-        } else {
-            tok = ((a >> GLZ_A_GLEN_SHIFT) & 31u) | (GLZ_SEL_TABLE << 29);
-        }
+        /* Everything any of the cases below could want is asked for at once (the addresses
+         * are in range whatever the flags say; what a case does not use is stale data that is
+         * never looked at) and the choice is a chain of selects: two LDS round trips instead
+         * of one per nested test.  Same precedence as the walk's: a stop it resolved itself,
+         * a run, the nearest stored position with this hash, the second nearest, the table. */
+        const uint32_t w1 = ins32[n1 >> 5], w2 = ins32[n2 >> 5];
+        const uint32_t slow_tok = sh.tok[p], gi = sh.g_idist[p], gp = sh.g_pdist[p], tp = sh.tok_pdist[p];
+        const bool slow = (sh.slow[p >> 6] >> lane) & 1;
+        const bool s1 = (a & GLZ_A_P1V) && ((w1 >> (n1 & 31u)) & 1u);
+        const bool s2 = (a & GLZ_A_P2V) && ((w2 >> (n2 & 31u)) & 1u);
+        uint32_t tok = ((a >> GLZ_A_GLEN_SHIFT) & 31u) | (GLZ_SEL_TABLE << 29);
+        tok = s2 ? ((b >> GLZ_B_LEN2_SHIFT) & 31u) | (GLZ_SEL_P2 << 29) : tok;
+        tok = s1 ? ((a >> GLZ_A_LEN1_SHIFT) & 31u) | (GLZ_SEL_P1 << 29) : tok;
+        tok = (a & GLZ_A_RLE) ? (b & 0x1ffu) | (GLZ_SEL_RUN << 29) : tok;
+        tok = slow ? slow_tok : tok;
         const uint32_t sel = tok >> 29;
-        if (sel == GLZ_SEL_P1) {
-            pdist = (uint32_t)p - n1;
-        } else if (sel == GLZ_SEL_P2) {
-            pdist = (uint32_t)p - n2;
-        } else if (sel == GLZ_SEL_TABLE) {
-            idist = sh.g_idist[p];
-            pdist = sh.g_pdist[p];
-        } else if (sel == GLZ_SEL_RUN) {
-            pdist = 1;
-        } else {
-            pdist = sh.tok_pdist[p];
-        }
+        pdist = sel == GLZ_SEL_P1 ? (uint32_t)p - n1
+              : sel == GLZ_SEL_P2 ? (uint32_t)p - n2
+              : sel == GLZ_SEL_TABLE ? gp
+              : sel == GLZ_SEL_RUN ? 1u : tp;
+        idist = sel == GLZ_SEL_TABLE ? gi : 0u;
         if (idist == 0) {
             pdist--; /* glz_encode_tmpl.c:389-391 */
         }
@@ -1596,12 +1592,7 @@ __device__ __forceinline__ void glz_window_emit(const GlzDevJob &job, uint32_t s
 
     EMIT_STAMP(2);
     /* (3) byte offsets: prefix sum over the 256 positions */
-    uint32_t incl = bytes;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t up = __shfl_up(incl, (unsigned)d);
-        incl += lane >= d ? up : 0u;
-    }
+    const uint32_t incl = wave_scan_inclusive(bytes, lane); /* six DPP adds, no LDS round trips */
     if (lane == 63) {
         sh.wave_sum[w] = incl;
     }
