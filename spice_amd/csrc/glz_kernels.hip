@@ -919,31 +919,30 @@ __device__ __forceinline__ void glz_window_scan(const GlzDevJob &job, const GlzD
     for (int k = 0; k < GLZ_K; k++) {
         mine[k] = sh.tile[p + 1 + k] & T::MASK;
     }
-    if (n1 >= 0) {
-        int len = 0;
-        bool run = true;
+    {
+        /* both candidates' pixels are asked for in one go, whether a lane has them or not
+         * (a lane without reads its own position), and what a lane lacks is masked out at
+         * the end: one LDS round trip and no divergent blocks */
+        const int q1 = n1 >= 0 ? n1 : p, q2 = n2 >= 0 ? n2 : p;
+        int len1 = 0, len2 = 0;
+        bool run1 = true, run2 = true;
 #pragma unroll
         for (int k = 0; k < GLZ_K; k++) {
-            run = run && k < maxn && (sh.tile[n1 + 1 + k] & T::MASK) == mine[k];
-            len += run ? 1 : 0;
+            const uint32_t t1 = sh.tile[q1 + 1 + k] & T::MASK, t2 = sh.tile[q2 + 1 + k] & T::MASK;
+            run1 = run1 && k < maxn && t1 == mine[k];
+            run2 = run2 && k < maxn && t2 == mine[k];
+            len1 += run1 ? 1 : 0;
+            len2 += run2 ? 1 : 0;
         }
-        const bool maxed = len == GLZ_K && GLZ_K < maxn;
-        A |= GLZ_A_P1V | ((n1 >> 6) == (p >> 6) ? GLZ_A_P1SAME : 0u) | ((uint32_t)n1 << GLZ_A_P1_SHIFT) |
-             ((uint32_t)glz_accept_near<MODE>(len) << GLZ_A_LEN1_SHIFT) | (maxed ? GLZ_A_MAX1 : 0u);
-    }
-    if (n2 >= 0) {
-        int len = 0;
-        bool run = true;
-#pragma unroll
-        for (int k = 0; k < GLZ_K; k++) {
-            run = run && k < maxn && (sh.tile[n2 + 1 + k] & T::MASK) == mine[k];
-            len += run ? 1 : 0;
-        }
-        const bool maxed = len == GLZ_K && GLZ_K < maxn;
+        const bool maxed1 = len1 == GLZ_K && GLZ_K < maxn, maxed2 = len2 == GLZ_K && GLZ_K < maxn;
+        const uint32_t a1 = GLZ_A_P1V | ((n1 >> 6) == (p >> 6) ? GLZ_A_P1SAME : 0u) | ((uint32_t)n1 << GLZ_A_P1_SHIFT) |
+                            ((uint32_t)glz_accept_near<MODE>(len1) << GLZ_A_LEN1_SHIFT) | (maxed1 ? GLZ_A_MAX1 : 0u);
         /* a third position with this hash is not looked for: take it that one exists */
-        A |= GLZ_A_P2V | GLZ_A_MORE | ((n2 >> 6) == (p >> 6) ? GLZ_A_P2SAME : 0u);
-        B = (uint32_t)n2 | ((uint32_t)glz_accept_near<MODE>(len) << GLZ_B_LEN2_SHIFT) |
-            (maxed ? GLZ_B_MAX2 : 0u);
+        const uint32_t a2 = GLZ_A_P2V | GLZ_A_MORE | ((n2 >> 6) == (p >> 6) ? GLZ_A_P2SAME : 0u);
+        const uint32_t b2 = (uint32_t)n2 | ((uint32_t)glz_accept_near<MODE>(len2) << GLZ_B_LEN2_SHIFT) |
+                            (maxed2 ? GLZ_B_MAX2 : 0u);
+        A |= (n1 >= 0 ? a1 : 0u) | (n2 >= 0 ? a2 : 0u);
+        B = n2 >= 0 ? b2 : B;
     }
 
     SCAN_STAMP(3);
