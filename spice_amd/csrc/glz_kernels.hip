@@ -49,6 +49,12 @@
 #define GLZ_SEG_CACHE 56                  /* segment slots mirrored in LDS (what 20 KB per workgroup leave) */
 #endif
 #define GLZ_KEYS 256                      /* rows of the same-hash bitmap */
+/* Word v (32 positions) of a key's row.  Rows are eight words, so with the words in their
+ * natural places every lane of a wavefront that reads "its row's word v" would land in one
+ * of four LDS banks (v, v + 8, v + 16, v + 24): a 16-way conflict on each of the kernel's
+ * hottest LDS accesses.  The words of a row are stored rotated by key / 4, which spreads
+ * the same access over all 32 banks. */
+#define GLZ_BM(key, v) ((key) * 8u + (((v) + ((key) >> 2)) & 7u))
 #define GLZ_NO_HASH 0xffffffffu
 
 /* first scan word of a position */
@@ -782,11 +788,11 @@ __device__ __forceinline__ void glz_window_scan(const GlzDevJob &job, const GlzD
     const uint32_t h = glz_hash3<MODE>(c0, c1, c2);
     const bool rle = act && q > 0 && cm1 == c0 && c0 == c1 && c1 == c2;
     const bool look = act && !rle;
-    uint32_t *row = &sh.bitmap[(h & (GLZ_KEYS - 1)) * 8];
+    const uint32_t key = h & (GLZ_KEYS - 1);
 
     sh.hash[p] = h;
     if (hv) {
-        atomicOr(&row[p >> 5], 1u << (p & 31));
+        atomicOr(&sh.bitmap[GLZ_BM(key, (uint32_t)p >> 5)], 1u << (p & 31));
     }
     /* the table probe travels while the window candidates are worked out */
     uint2 he = make_uint2(0, 0);
@@ -819,7 +825,7 @@ __device__ __forceinline__ void glz_window_scan(const GlzDevJob &job, const GlzD
     int n1 = -1, n2 = -1;
     if (look) {
         for (int v = p >> 5; v >= 0 && n2 < 0; v--) {
-            uint32_t bits = row[v];
+            uint32_t bits = sh.bitmap[GLZ_BM(key, (uint32_t)v)];
             if (v == (p >> 5)) {
                 bits &= (1u << (p & 31)) - 1;
             }
@@ -1465,9 +1471,9 @@ __device__ __forceinline__ void glz_window_emit(const GlzDevJob &job, uint32_t s
             /* the last match's stores beyond the window are made after these, in
              * program order, so they win a shared slot by themselves */
             bool dominated = false;
-            const uint32_t *row = &sh.bitmap[(my_h & (GLZ_KEYS - 1)) * 8];
+            const uint32_t key = my_h & (GLZ_KEYS - 1);
             for (int v = p >> 5; v < 8 && !dominated; v++) {
-                uint32_t bits = row[v] & ins32[v];
+                uint32_t bits = sh.bitmap[GLZ_BM(key, (uint32_t)v)] & ins32[v];
                 if (v == (p >> 5)) {
                     bits &= ~((2u << (p & 31)) - 1);
                 }
@@ -1641,7 +1647,7 @@ __device__ __forceinline__ void glz_window_emit(const GlzDevJob &job, uint32_t s
     }
     /* the bitmap is clean again for the next window */
     if (my_hv) {
-        sh.bitmap[(my_h & (GLZ_KEYS - 1)) * 8 + (p >> 5)] = 0;
+        sh.bitmap[GLZ_BM(my_h & (GLZ_KEYS - 1), (uint32_t)p >> 5)] = 0;
     }
     EMIT_STAMP(4);
 }
