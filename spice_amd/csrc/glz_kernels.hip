@@ -862,62 +862,58 @@ __device__ __forceinline__ void glz_window_scan(const GlzDevJob &job, const GlzD
         r[k] = 0;
     }
 #endif
-    if (look) {
-        /* the stores the previous window's last match left for positions ip-2 and
-         * ip-1 are the newest entries of their slots, whatever the probe saw */
-        if ((pend & 2u) && h == th1) {
-            he = make_uint2(seg_idx, (uint32_t)(ip - 1));
-        } else if ((pend & 1u) && h == th0) {
-            he = make_uint2(seg_idx, (uint32_t)(ip - 2));
-        }
+    {
+        /* Straight-line up to the pixel requests: every test is a select on values all
+         * lanes work out (a lane that does not look at the table works on the zero entry
+         * it holds and is masked out by `look` at the end), so that the exec mask is
+         * touched once, round the requests themselves. */
+        /* the stores the previous window's last match left for positions ip-2 and ip-1
+         * are the newest entries of their slots, whatever the probe saw */
+        const bool o1 = (pend & 2u) && h == th1, o0 = (pend & 1u) && h == th0;
+        he.x = (o1 || o0) ? seg_idx : he.x;
+        he.y = o1 ? (uint32_t)(ip - 1) : (o0 ? (uint32_t)(ip - 2) : he.y);
         const GlzDevSeg rs = glz_seg(job, sh, he.x);
         const bool valid =
             he.x == seg_idx ||
             ((rs.flags & GLZ_SEG_USED) && (rs.flags & GLZ_SEG_ALIVE) &&
              (rs.flags & GLZ_SEG_TYPE_MASK) == (cs.flags & GLZ_SEG_TYPE_MASK) &&
              rs.pixels_so_far <= cs.pixels_so_far && job.head_psf <= rs.pixels_so_far);
-        if (valid && (int64_t)he.y <= (int64_t)rs.nunits - T::MIN_REF) {
-            const uint64_t idist = cs.image_id - rs.image_id;
-            uint64_t pdist;
-            if (idist == 0) {
-                pdist = ((uint64_t)q + cs.pixels_so_far) - ((uint64_t)he.y + rs.pixels_so_far);
+        const uint64_t idist = cs.image_id - rs.image_id;
+        const uint64_t pdist = idist == 0 ? ((uint64_t)q + cs.pixels_so_far) - ((uint64_t)he.y + rs.pixels_so_far)
+                                          : (uint64_t)he.y + rs.img_first_delta;
+        const int ref = (int)he.y;
+        const int rmax = (int)rs.nunits - ref;
+        const int mk = rmax < maxn ? rmax : maxn;
+        gok = look && valid && (int64_t)he.y <= (int64_t)rs.nunits - T::MIN_REF && pdist != 0 &&
+              pdist < 33554432ull && idist <= 16777215ull;
+        capped = mk > GLZ_K;
+        maxk = capped ? GLZ_K : mk;
+        gidist = (uint32_t)idist;
+        gpdist = (uint32_t)pdist;
+        if (gok) {
+            const GLZ_GLOBAL uint8_t *rbase = glz_seg_base(job, he.x, rs);
+            if (MODE == GLZ_MODE_RGB32 && GLZ_K == 8 && maxk == GLZ_K) {
+                /* eight whole pixels lie ahead: two 16-byte requests instead of eight
+                 * of four bytes -- every request of the wavefront, wide or narrow,
+                 * is a pass through the CU's one address unit over up to 64 lines */
+                const GLZ_GLOBAL glz_u32x4_u *w16 = (const GLZ_GLOBAL glz_u32x4_u *)(rbase + (size_t)ref * 4);
+                const glz_u32x4 lo = w16[0], hi = w16[1];
+                r[0] = lo[0];
+                r[1] = lo[1];
+                r[2] = lo[2];
+                r[3] = lo[3];
+                r[GLZ_K - 4] = hi[0];
+                r[GLZ_K - 3] = hi[1];
+                r[GLZ_K - 2] = hi[2];
+                r[GLZ_K - 1] = hi[3];
             } else {
-                pdist = (uint64_t)he.y + rs.img_first_delta;
-            }
-            if (pdist != 0 && pdist < 33554432ull && idist <= 16777215ull) {
-                const GLZ_GLOBAL uint8_t *rbase = glz_seg_base(job, he.x, rs);
-                const int ref = (int)he.y;
-                const int rmax = (int)rs.nunits - ref;
-                maxk = rmax < maxn ? rmax : maxn;
-                capped = maxk > GLZ_K;
-                maxk = capped ? GLZ_K : maxk;
-                gok = true;
-                gidist = (uint32_t)idist;
-                gpdist = (uint32_t)pdist;
-                if (MODE == GLZ_MODE_RGB32 && GLZ_K == 8 && maxk == GLZ_K) {
-                    /* eight whole pixels lie ahead: two 16-byte requests instead of eight
-                     * of four bytes -- every request of the wavefront, wide or narrow,
-                     * is a pass through the CU's one address unit over up to 64 lines */
-                    const GLZ_GLOBAL glz_u32x4_u *w16 = (const GLZ_GLOBAL glz_u32x4_u *)(rbase + (size_t)ref * 4);
-                    const glz_u32x4 lo = w16[0], hi = w16[1];
-                    r[0] = lo[0];
-                    r[1] = lo[1];
-                    r[2] = lo[2];
-                    r[3] = lo[3];
-                    r[GLZ_K - 4] = hi[0];
-                    r[GLZ_K - 3] = hi[1];
-                    r[GLZ_K - 2] = hi[2];
-                    r[GLZ_K - 1] = hi[3];
-                } else {
 #pragma unroll
-                    for (int k = 0; k < GLZ_K; k++) {
-                        r[k] = glz_load_px<MODE>(rbase, ref + (k < maxk ? k : 0));
-                    }
+                for (int k = 0; k < GLZ_K; k++) {
+                    r[k] = glz_load_px<MODE>(rbase, ref + (k < maxk ? k : 0));
                 }
             }
         }
     }
-
     SCAN_STAMP(2);
     /* (3) the window candidates against the LDS tile */
     uint32_t mine[GLZ_K];
