@@ -1600,6 +1600,13 @@ __device__ __forceinline__ void glz_window_emit(const GlzDevJob &job, uint32_t s
     __syncthreads();
     const uint32_t ws0 = sh.wave_sum[0], ws1 = sh.wave_sum[1], ws2 = sh.wave_sum[2], ws3 = sh.wave_sum[3];
     uint32_t off = op_in + incl - bytes + (w > 0 ? ws0 : 0u) + (w > 1 ? ws1 : 0u) + (w > 2 ? ws2 : 0u);
+    /* the cursor moves on here, while the four sums are at hand: held until the end of the
+     * phase they are four registers the allocator spills and reloads in every window
+     * (every lane read the old cursor before the barrier above) */
+    if (tid == 0) {
+        sh.op = op_in + ws0 + ws1 + ws2 + ws3;
+        sh.copy = run_end & 31;
+    }
 
     EMIT_STAMP(3);
     /* (4) write.  A token that does not fit whole is not written at all: the image
@@ -1636,10 +1643,6 @@ __device__ __forceinline__ void glz_window_emit(const GlzDevJob &job, uint32_t s
                 glz_put(glz_out(job), job.out_cap, o2 + 1 + t, 255u);
             }
         }
-    }
-    if (tid == 0) {
-        sh.op = op_in + ws0 + ws1 + ws2 + ws3;
-        sh.copy = run_end & 31;
     }
     /* the bitmap is clean again for the next window */
     if (my_hv) {
