@@ -712,8 +712,15 @@ __device__ __forceinline__ void jpeg_strip_body(const JpegDevJob &job, const uin
     const int hy = __builtin_amdgcn_readfirstlane(has_halo ? hlin / job.mcu_cols : 0);
     const int hx = __builtin_amdgcn_readfirstlane(has_halo ? hlin % job.mcu_cols : 0);
 
-    for (int i = tid; i < JHUFF_WORDS; i += JT) {
-        huff[i] = huff_g[i];
+    /* The Huffman tables are asked for here and put into LDS after the pixel phase: a
+     * copy loop at this point is up to three global round trips one after the other
+     * (load, wait, store) before the first pixel is even requested. */
+    constexpr int kHuffTurns = (JHUFF_WORDS + JT - 1) / JT;
+    uint32_t huff_w[kHuffTurns];
+#pragma unroll
+    for (int k = 0; k < kHuffTurns; k++) {
+        const int i = tid + k * JT;
+        huff_w[k] = i < JHUFF_WORDS ? huff_g[i] : 0u;
     }
     for (int i = tid; i < (JT / 64) * JRING_WORDS; i += JT) {
         rings[i] = 0;
@@ -734,6 +741,13 @@ __device__ __forceinline__ void jpeg_strip_body(const JpegDevJob &job, const uin
     default:
         jpeg_load_tiles_wide<6>(job, ytile, cbtile, crtile, tid, ns, has_halo, hx, hy, mx0, my);
         break;
+    }
+#pragma unroll
+    for (int k = 0; k < kHuffTurns; k++) {
+        const int i = tid + k * JT;
+        if (i < JHUFF_WORDS) {
+            huff[i] = huff_w[k];
+        }
     }
     __syncthreads();
 
