@@ -679,7 +679,7 @@ __device__ __forceinline__ void jpeg_load_tiles_wide(const JpegDevJob &job, uint
  * (an intermediate state of the Huffman walk) was never committed, so its fault is not
  * explained; what is shipped has no call in either strip kernel. */
 template <bool IFAST>
-__device__ __forceinline__ void jpeg_strip_body(const JpegDevJob &job, const uint32_t *huff_g, int group)
+__device__ __forceinline__ void jpeg_strip_body(const JpegDevJob &job, const JpegDevJob &full, const uint32_t *huff_g, int group)
 {
     /* the pixel tiles are dead once every lane holds its block in registers, so the
      * coefficients take their place: with the tables and bit rings 39 KB per workgroup, four workgroups per CU */
@@ -842,8 +842,8 @@ __device__ __forceinline__ void jpeg_strip_body(const JpegDevJob &job, const uin
          * multiply.  (Skipping the division where a whole wavefront's coefficients
          * round to zero, as the integer quantiser did, no longer pays: the votes cost
          * what the six instructions of a pair do.) */
-        const JPEG_CONST jf8 *hf = (const JPEG_CONST jf8 *)(uintptr_t)(pass == 0 ? job.qhalf_y : job.qhalf_c);
-        const JPEG_CONST jf8 *rc = (const JPEG_CONST jf8 *)(uintptr_t)(pass == 0 ? job.rcp_y : job.rcp_c);
+        const JPEG_CONST jf8 *hf = (const JPEG_CONST jf8 *)(uintptr_t)(pass == 0 ? full.qhalf_y : full.qhalf_c);
+        const JPEG_CONST jf8 *rc = (const JPEG_CONST jf8 *)(uintptr_t)(pass == 0 ? full.rcp_y : full.rcp_c);
         if (mine) {
             /* everything but the sign bit, in a vector register: the sign transfer
              * below is then one v_bfi_b32 whose only scalar operand is d/2 */
@@ -928,7 +928,7 @@ __device__ __forceinline__ void jpeg_strip_body(const JpegDevJob &job, const uin
         const int m0 = wave * JPEG_STRIP_MCUS, m1 = min(m0 + JPEG_STRIP_MCUS, nm);
         uint32_t *ring = rings + wave * JRING_WORDS;
         JPEG_GLOBAL uint32_t *out_words =
-            (JPEG_GLOBAL uint32_t *)(uintptr_t)(job.strip_buf + (size_t)strip * job.strip_stride);
+            (JPEG_GLOBAL uint32_t *)(uintptr_t)(full.strip_buf + (size_t)strip * full.strip_stride);
         const uint16_t *coef16 = (const uint16_t *)coef;
         uint32_t bits = 0, flushed = 0; /* stream bits so far; words already in the slot */
 
@@ -1130,7 +1130,7 @@ __device__ __forceinline__ void jpeg_strip_body(const JpegDevJob &job, const uin
             }
         }
         if (lane == 0) {
-            job.strip_bits[strip] = bits;
+            full.strip_bits[strip] = bits;
         }
     }
 }
@@ -1140,13 +1140,32 @@ template <bool IFAST>
 __global__ void __launch_bounds__(JT) JPEG_FOUR_PER_CU
 jpeg_strip_kernel(const JpegDevJob *jobs, const uint32_t *huff)
 {
-    const JpegDevJob &job = jobs[blockIdx.y];
+    const JpegDevJob &full = jobs[blockIdx.y];
+    /* The image's geometry, fourteen words at the record's head, is copied here in one
+     * go (a few wide scalar loads and one wait) and the loaders and the set-up work on
+     * the copy: read field by field where each is first used, they were seven scalar
+     * round trips one behind the other before the first pixel request.  Only these
+     * members of the copy are ever set or read; the tables and the scratch pointers
+     * stay behind `full`. */
+    JpegDevJob job;
+    job.pixels = full.pixels;
+    job.stride = full.stride;
+    job.width = full.width;
+    job.height = full.height;
+    job.format = full.format;
+    job.dct = full.dct;
+    job.mcu_cols = full.mcu_cols;
+    job.mcu_rows = full.mcu_rows;
+    job.strips_per_row = full.strips_per_row;
+    job.nstrips = full.nstrips;
+    job.yb_w = full.yb_w;
+    job.yb_h = full.yb_h;
     const int group = (int)blockIdx.x;
     const int groups_per_row = (job.strips_per_row + JPEG_GROUP_STRIPS - 1) / JPEG_GROUP_STRIPS;
     if (group >= groups_per_row * job.mcu_rows || (job.dct != 0) != IFAST) {
         return;
     }
-    jpeg_strip_body<IFAST>(job, huff, group);
+    jpeg_strip_body<IFAST>(job, full, huff, group);
 }
 
 /* Exclusive scan of strip_bits into strip_bitoff (64-bit), one workgroup per job:
