@@ -258,6 +258,8 @@ static bool build_job(JpegDevJob *j, int format, int width, int height, long str
     j->nstrips = j->strips_per_row * j->mcu_rows;
     j->yb_w = (width + 7) / 8;
     j->yb_h = (height + 7) / 8;
+    j->groups_per_row = (j->strips_per_row + JPEG_GROUP_STRIPS - 1) / JPEG_GROUP_STRIPS;
+    j->groups_rcp = (uint32_t)((1ull << 32) / (uint64_t)j->groups_per_row + 1);
     uint16_t qy[64], qc[64];
     quant_table(kLumaQ, quality, qy);
     quant_table(kChromaQ, quality, qc);

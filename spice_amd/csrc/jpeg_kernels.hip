@@ -700,17 +700,17 @@ __device__ __forceinline__ void jpeg_strip_body(const JpegDevJob &job, const Jpe
     /* Where the group lies is the same for every lane, but the divisions are done
      * in vector registers: moved to scalar ones here, or the pixel loaders, which
      * use them for every item, fetch them back from scratch memory each time. */
-    const int groups_per_row = (job.strips_per_row + JPEG_GROUP_STRIPS - 1) / JPEG_GROUP_STRIPS;
-    const int my = __builtin_amdgcn_readfirstlane(group / groups_per_row);
-    const int first_strip = __builtin_amdgcn_readfirstlane((group % groups_per_row) * JPEG_GROUP_STRIPS);
+    /* group / groups_per_row by the record's reciprocal: one scalar multiply instead of
+     * a division worked out in vector registers at the head of every workgroup */
+    const int my = job.groups_per_row == 1 ? group : (int)(((uint64_t)(uint32_t)group * job.groups_rcp) >> 32);
+    const int first_strip = (group - my * job.groups_per_row) * JPEG_GROUP_STRIPS;
     const int mx0 = first_strip * JPEG_STRIP_MCUS;
     const int nm = min(JG_MCUS, job.mcu_cols - mx0);
     const bool has_halo = group != 0;
     const int ns = nm + 1;
-    /* the MCU coded just before this strip */
-    const int hlin = my * job.mcu_cols + mx0 - 1;
-    const int hy = __builtin_amdgcn_readfirstlane(has_halo ? hlin / job.mcu_cols : 0);
-    const int hx = __builtin_amdgcn_readfirstlane(has_halo ? hlin % job.mcu_cols : 0);
+    /* the MCU coded just before this strip: the one to the left, or the last of the row above */
+    const int hy = !has_halo ? 0 : mx0 > 0 ? my : my - 1;
+    const int hx = !has_halo ? 0 : mx0 > 0 ? mx0 - 1 : job.mcu_cols - 1;
 
     /* The Huffman tables are asked for here and put into LDS after the pixel phase: a
      * copy loop at this point is up to three global round trips one after the other
@@ -1141,7 +1141,7 @@ __global__ void __launch_bounds__(JT) JPEG_FOUR_PER_CU
 jpeg_strip_kernel(const JpegDevJob *jobs, const uint32_t *huff)
 {
     const JpegDevJob &full = jobs[blockIdx.y];
-    /* The image's geometry, fourteen words at the record's head, is copied here in one
+    /* The image's geometry, sixteen words at the record's head, is copied here in one
      * go (a few wide scalar loads and one wait) and the loaders and the set-up work on
      * the copy: read field by field where each is first used, they were seven scalar
      * round trips one behind the other before the first pixel request.  Only these
@@ -1160,9 +1160,10 @@ jpeg_strip_kernel(const JpegDevJob *jobs, const uint32_t *huff)
     job.nstrips = full.nstrips;
     job.yb_w = full.yb_w;
     job.yb_h = full.yb_h;
+    job.groups_per_row = full.groups_per_row;
+    job.groups_rcp = full.groups_rcp;
     const int group = (int)blockIdx.x;
-    const int groups_per_row = (job.strips_per_row + JPEG_GROUP_STRIPS - 1) / JPEG_GROUP_STRIPS;
-    if (group >= groups_per_row * job.mcu_rows || (job.dct != 0) != IFAST) {
+    if (group >= job.groups_per_row * job.mcu_rows || (job.dct != 0) != IFAST) {
         return;
     }
     jpeg_strip_body<IFAST>(job, full, huff, group);
