@@ -1148,20 +1148,25 @@ jpeg_strip_kernel(const JpegDevJob *jobs, const uint32_t *huff)
      * members of the copy are ever set or read; the tables and the scratch pointers
      * stay behind `full`. */
     JpegDevJob job;
-    job.pixels = full.pixels;
-    job.stride = full.stride;
-    job.width = full.width;
-    job.height = full.height;
-    job.format = full.format;
-    job.dct = full.dct;
-    job.mcu_cols = full.mcu_cols;
-    job.mcu_rows = full.mcu_rows;
-    job.strips_per_row = full.strips_per_row;
-    job.nstrips = full.nstrips;
-    job.yb_w = full.yb_w;
-    job.yb_h = full.yb_h;
-    job.groups_per_row = full.groups_per_row;
-    job.groups_rcp = full.groups_rcp;
+    {
+        /* read as constant memory: the record is not written while the kernel runs, and
+         * the compiler may then use scalar loads whatever stands in front of them */
+        const JPEG_CONST JpegDevJob &head = *(const JPEG_CONST JpegDevJob *)(uintptr_t)&full;
+        job.pixels = head.pixels;
+        job.stride = head.stride;
+        job.width = head.width;
+        job.height = head.height;
+        job.format = head.format;
+        job.dct = head.dct;
+        job.mcu_cols = head.mcu_cols;
+        job.mcu_rows = head.mcu_rows;
+        job.strips_per_row = head.strips_per_row;
+        job.nstrips = head.nstrips;
+        job.yb_w = head.yb_w;
+        job.yb_h = head.yb_h;
+        job.groups_per_row = head.groups_per_row;
+        job.groups_rcp = head.groups_rcp;
+    }
     const int group = (int)blockIdx.x;
     if (group >= job.groups_per_row * job.mcu_rows || (job.dct != 0) != IFAST) {
         return;
