@@ -695,6 +695,13 @@ __device__ __forceinline__ void jpeg_strip_body(const JpegDevJob &job, const Jpe
     __shared__ int dcq[JSLOTS * 6];
     __shared__ uint32_t huff[JHUFF_WORDS];
     __shared__ uint32_t rings[(JT / 64) * JRING_WORDS];
+    /* the quantiser's constants as the record holds them: rcp_y, rcp_c, qhalf_y, qhalf_c */
+    __shared__ __align__(16) float qtab[4 * 64];
+    static_assert(JT == 4 * 64, "a lane stages one of the quantiser's 256 constants");
+    static_assert(offsetof(JpegDevJob, rcp_c) == offsetof(JpegDevJob, rcp_y) + 256 &&
+                      offsetof(JpegDevJob, qhalf_y) == offsetof(JpegDevJob, rcp_y) + 512 &&
+                      offsetof(JpegDevJob, qhalf_c) == offsetof(JpegDevJob, rcp_y) + 768,
+                  "the four tables lie side by side");
 
     const int tid = (int)threadIdx.x;
     /* Where the group lies is the same for every lane, but the divisions are done
@@ -722,6 +729,10 @@ __device__ __forceinline__ void jpeg_strip_body(const JpegDevJob &job, const Jpe
         const int i = tid + k * JT;
         huff_w[k] = i < JHUFF_WORDS ? huff_g[i] : 0u;
     }
+    /* ... and so are the quantiser's constants, one per lane: read row by row through
+     * the scalar unit in the middle of the quantiser, each row was a scalar round trip
+     * the wavefront sat out */
+    const float qtab_w = full.rcp_y[tid];
     for (int i = tid; i < (JT / 64) * JRING_WORDS; i += JT) {
         rings[i] = 0;
     }
@@ -749,6 +760,7 @@ __device__ __forceinline__ void jpeg_strip_body(const JpegDevJob &job, const Jpe
             huff[i] = huff_w[k];
         }
     }
+    qtab[tid] = qtab_w;
     __syncthreads();
 
     /* ---- phase 2: one lane per block.  Luma lanes are ordered so that a wave
@@ -826,56 +838,46 @@ __device__ __forceinline__ void jpeg_strip_body(const JpegDevJob &job, const Jpe
             }
         }
     }
-    /* The divisors come through the scalar unit, a table at a time: luma lanes
-     * first, then chroma lanes (only one wavefront of the four holds both), so
-     * no vector register is spent on the constants. */
-#pragma unroll
-    for (int pass = 0; pass < 2; pass++) {
-        const bool mine = have && real && ((bidx < 4) == (pass == 0));
-        if (__ballot(mine) == 0) {
-            continue;
-        }
-        /* jcdctmgr.c's sign(v) x floor((|v| + d/2) / d) on the pairs the DCT left:
-         * a = v + copysign(d/2, v); a x rcp, with rcp the float at or just above
-         * 1/d, lies at or above a/d and below the next integer (|a| < 2^18), so
-         * truncating it is the division; two coefficients share the add and the
-         * multiply.  (Skipping the division where a whole wavefront's coefficients
-         * round to zero, as the integer quantiser did, no longer pays: the votes cost
-         * what the six instructions of a pair do.) */
-        const JPEG_CONST jf8 *hf = (const JPEG_CONST jf8 *)(uintptr_t)(pass == 0 ? full.qhalf_y : full.qhalf_c);
-        const JPEG_CONST jf8 *rc = (const JPEG_CONST jf8 *)(uintptr_t)(pass == 0 ? full.rcp_y : full.rcp_c);
-        if (mine) {
-            /* everything but the sign bit, in a vector register: the sign transfer
-             * below is then one v_bfi_b32 whose only scalar operand is d/2 */
-            uint32_t magn = 0x7fffffffu;
+    /* jcdctmgr.c's sign(v) x floor((|v| + d/2) / d) on the pairs the DCT left:
+     * a = v + copysign(d/2, v); a x rcp, with rcp the float at or just above
+     * 1/d, lies at or above a/d and below the next integer (|a| < 2^18), so
+     * truncating it is the division; two coefficients share the add and the
+     * multiply.  (Skipping the division where a whole wavefront's coefficients
+     * round to zero, as the integer quantiser did, no longer pays: the votes cost
+     * what the six instructions of a pair do.)  The constants come from LDS a row of
+     * eight at a time, the same addresses for all luma lanes and for all chroma lanes. */
+    if (have && real) {
+        /* everything but the sign bit, in a vector register: the sign transfer
+         * below is then one v_bfi_b32 */
+        uint32_t magn = 0x7fffffffu;
 #ifndef SPICE_WAVE_SIM
-            asm volatile("" : "+v"(magn));
+        asm volatile("" : "+v"(magn));
 #endif
-            /* The quotients go straight to the block's place in LDS, 16 bits each at
-             * its zigzag position, as they are made: none of them stays in a
-             * register waiting for its neighbour in zigzag order. */
-            constexpr int izz[64] = {JIZZ_LIST};
-            uint16_t *dst16 = (uint16_t *)(coef + ((slot > 0 ? slot - 1 : JG_MCUS) * 6 + bidx) * JCOEF_STRIDE);
+        /* The quotients go straight to the block's place in LDS, 16 bits each at
+         * its zigzag position, as they are made: none of them stays in a
+         * register waiting for its neighbour in zigzag order. */
+        constexpr int izz[64] = {JIZZ_LIST};
+        uint16_t *dst16 = (uint16_t *)(coef + ((slot > 0 ? slot - 1 : JG_MCUS) * 6 + bidx) * JCOEF_STRIDE);
+        const jf8 *rc = (const jf8 *)&qtab[bidx < 4 ? 0 : 64];
+        const jf8 *hf = (const jf8 *)&qtab[bidx < 4 ? 128 : 192];
 #pragma unroll
-            for (int g = 0; g < 8; g++) {
-                /* a row of eight coefficients: its constants in two scalar loads */
-                const jf8 hf8 = hf[g], rc8 = rc[g];
+        for (int g = 0; g < 8; g++) {
+            const jf8 hf8 = hf[g], rc8 = rc[g];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int j = g * 4 + u;
-                    const jf2 t = pf[j];
-                    /* sign of t over d/2: t ^ ((h ^ t) & magn), one v_bfi_b32 */
-                    const uint32_t b0 = jpeg_fbits(t[0]), b1 = jpeg_fbits(t[1]);
-                    const uint32_t s0 = b0 ^ ((jpeg_fbits(hf8[2 * u]) ^ b0) & magn);
-                    const uint32_t s1 = b1 ^ ((jpeg_fbits(hf8[2 * u + 1]) ^ b1) & magn);
-                    const jf2 a = t + jpeg_f2(jpeg_bitsf(s0), jpeg_bitsf(s1));
-                    const jf2 q = a * jpeg_f2(rc8[2 * u], rc8[2 * u + 1]);
-                    const int q0 = (int)q[0], q1 = (int)q[1];
-                    dst16[izz[2 * j]] = (uint16_t)q0;
-                    dst16[izz[2 * j + 1]] = (uint16_t)q1;
-                    if (j == 0) {
-                        c[0] = q0;
-                    }
+            for (int u = 0; u < 4; u++) {
+                const int j = g * 4 + u;
+                const jf2 t = pf[j];
+                /* sign of t over d/2: t ^ ((h ^ t) & magn), one v_bfi_b32 */
+                const uint32_t b0 = jpeg_fbits(t[0]), b1 = jpeg_fbits(t[1]);
+                const uint32_t s0 = b0 ^ ((jpeg_fbits(hf8[2 * u]) ^ b0) & magn);
+                const uint32_t s1 = b1 ^ ((jpeg_fbits(hf8[2 * u + 1]) ^ b1) & magn);
+                const jf2 a = t + jpeg_f2(jpeg_bitsf(s0), jpeg_bitsf(s1));
+                const jf2 q = a * jpeg_f2(rc8[2 * u], rc8[2 * u + 1]);
+                const int q0 = (int)q[0], q1 = (int)q[1];
+                dst16[izz[2 * j]] = (uint16_t)q0;
+                dst16[izz[2 * j + 1]] = (uint16_t)q1;
+                if (j == 0) {
+                    c[0] = q0;
                 }
             }
         }
