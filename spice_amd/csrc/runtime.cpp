@@ -227,12 +227,10 @@ void timing_collect_locked()
 }
 } // namespace
 
-int timing_begin(const char *kernel_name, hipStream_t s)
+namespace {
+/* a pending entry for one launch of kernel_name, with its two events; g_time_mutex held */
+TimedLaunch &timing_entry_locked(const char *kernel_name, bool closed)
 {
-    std::lock_guard<std::mutex> lock(g_time_mutex);
-    if (!g_timing) {
-        return -1;
-    }
     int id = -1;
     for (size_t i = 0; i < g_time_names.size(); i++) {
         if (g_time_names[i] == kernel_name) {
@@ -247,11 +245,34 @@ int timing_begin(const char *kernel_name, hipStream_t s)
         snprintf(t.name, sizeof(t.name), "%s", kernel_name);
         g_time_acc.push_back(t);
     }
-    TimedLaunch t{id, g_time_next_id, false, take_event(), take_event()};
+    TimedLaunch t{id, g_time_next_id, closed, take_event(), take_event()};
     g_time_next_id = (g_time_next_id + 1) & 0x3fffffff;
-    hipEventRecord(t.a, s);
     g_time_pending.push_back(t);
+    return g_time_pending.back();
+}
+} // namespace
+
+int timing_begin(const char *kernel_name, hipStream_t s)
+{
+    std::lock_guard<std::mutex> lock(g_time_mutex);
+    if (!g_timing) {
+        return -1;
+    }
+    TimedLaunch &t = timing_entry_locked(kernel_name, false);
+    hipEventRecord(t.a, s);
     return t.id;
+}
+
+bool timing_events(const char *kernel_name, hipEvent_t *start, hipEvent_t *stop)
+{
+    std::lock_guard<std::mutex> lock(g_time_mutex);
+    if (!g_timing) {
+        return false;
+    }
+    TimedLaunch &t = timing_entry_locked(kernel_name, true);
+    *start = t.a;
+    *stop = t.b;
+    return true;
 }
 
 void timing_end(int token, hipStream_t s)

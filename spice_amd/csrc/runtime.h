@@ -62,6 +62,11 @@ void stat_add(int codec, uint64_t orig, uint64_t comp, uint64_t ns);
 /* Brackets one kernel launch with events when timing is enabled (no-ops otherwise). */
 int timing_begin(const char *kernel_name, hipStream_t s);
 void timing_end(int token, hipStream_t s);
+/* The same for a launch that records its own begin and end (hipExtLaunchKernelGGL's start
+ * and stop events): hands out the two events of a new entry and records nothing itself, so
+ * no event packet stands between the kernel and its neighbours on the stream.  False when
+ * timing is off. */
+bool timing_events(const char *kernel_name, hipEvent_t *start, hipEvent_t *stop);
 uint64_t now_ns();
 
 /* Host-pinned buffer with a device mirror, grown geometrically. */
