@@ -52,7 +52,9 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="glz1080", choices=WORKLOADS)
     ap.add_argument("--sessions", type=int, default=3072, help="GLZ display sessions per GPU")
-    ap.add_argument("--frames", type=int, default=16, help="MJPEG frames per step per GPU")
+    ap.add_argument("--frames", type=int, default=64,
+                    help="MJPEG frames (= streams) per step per GPU; 64 x 4K are 51 rounds of workgroups "
+                         "on the GPU's 1024 slots (16 are 12.7 rounds: 10 %% more time per frame)")
     ap.add_argument("--clients", type=int, default=8, help="multimon: four-monitor clients per GPU")
     ap.add_argument("--pool", type=int, default=256, help="distinct synthetic desktop sequences per GPU")
     ap.add_argument("--out-mb", type=float, default=2.0,
