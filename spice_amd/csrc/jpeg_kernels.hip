@@ -685,7 +685,7 @@ template <bool IFAST>
 __device__ __forceinline__ void jpeg_strip_body(const JpegDevJob &job, const JpegDevJob &full, const uint32_t *huff_g, int group)
 {
     /* the pixel tiles are dead once every lane holds its block in registers, so the
-     * coefficients take their place: with the tables and bit rings 39 KB per workgroup, four workgroups per CU */
+     * coefficients take their place: with the tables, the quantiser's constants and the bit rings 40 760 B per workgroup, four workgroups per CU */
     constexpr int kTileBytes = 16 * YT_STRIDE + 2 * 8 * CT_STRIDE;
     /* one MCU's worth more than the group has: where the halo MCU's lanes put the
      * coefficients nobody reads (only its DC values are wanted) */
@@ -1140,7 +1140,7 @@ __device__ __forceinline__ void jpeg_strip_body(const JpegDevJob &job, const Jpe
     }
 }
 
-/* Four workgroups per CU: 128 VGPRs (a few dwords of the DCT spill) and 39 KB of LDS each. */
+/* Four workgroups per CU: at most 128 VGPRs (106 / 112 used, nothing spilled) and 40 760 B of LDS each. */
 template <bool IFAST>
 __global__ void __launch_bounds__(JT) JPEG_FOUR_PER_CU
 jpeg_strip_kernel(const JpegDevJob *jobs, const uint32_t *huff)
