@@ -37,8 +37,9 @@ struct JpegDevJob {
     int32_t yb_w, yb_h;                 /* real luma blocks per row / column */
     int32_t groups_per_row;             /* strip groups (JPEG_GROUP_STRIPS strips) in an MCU row */
     uint32_t groups_rcp;                /* 2^32 / groups_per_row + 1: (group x this) >> 32 is the group's
-                                         * MCU row while group x groups_per_row < 2^32 (one group per
-                                         * row, where this would need 33 bits, is tested for) */
+                                         * MCU row while group x groups_per_row < 2^32 -- a JPEG has at
+                                         * most 4096 MCU rows of 103 groups -- (one group per row,
+                                         * where this would need 33 bits, is tested for) */
     int32_t div_y[64], div_c[64];       /* jcdctmgr divisors, natural order */
     float rcp_y[64], rcp_c[64];         /* the single-precision number at or just above 1 / divisor */
     float qhalf_y[64], qhalf_c[64];     /* divisor / 2 (integer division) */

@@ -117,6 +117,20 @@ def test_sim_negative_stride_and_capacity(sim, oracle):
     run_capacity_error(sim)
 
 
+def test_group_row_by_reciprocal_is_exact():
+    """The strip kernel finds a workgroup's MCU row as (group x groups_rcp) >> 32 with
+    groups_rcp = 2^32 / groups_per_row + 1 from the job record (jpeg_host.cpp build_job,
+    jpeg_kernels.hip jpeg_strip_body), one group per row being tested for apart.  The product
+    is the integer quotient while group x groups_per_row < 2^32; a JPEG is at most 65 535
+    pixels a side = 4096 MCUs = 103 groups of 40 MCUs a row and 4096 MCU rows, and every group
+    index of every such image is walked here."""
+    for gpr in range(2, 104):
+        rcp = (1 << 32) // gpr + 1
+        assert rcp < (1 << 32)
+        g = np.arange(gpr * 4096, dtype=np.uint64)
+        assert np.array_equal((g * np.uint64(rcp)) >> np.uint64(32), g // np.uint64(gpr)), gpr
+
+
 def test_quantiser_in_single_precision_is_exact():
     """the arithmetic claim behind the strip kernel's quantiser (jpeg_kernels.hip) and the tables
     jpeg_host.cpp fills: with rcp the single-precision number at or just above 1/d,
