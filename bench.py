@@ -837,6 +837,7 @@ def measure(cls, gpu, dist, args, geo, steps, warmup, e2e=True, cpu=True, **kw):
     st = gpu.stats(wl.codec)                 # the timed steps only
     gathered = dist.gather_i64([st["count"], st["orig_bytes"], st["comp_bytes"], st["total_ns"]])
     part = {"workload": wl.config()["workload"], "value": round(units / dt / 1e6, 1), "unit": "Mpixels/s",
+            "steps": steps, "warmup": warmup,
             "ms_per_step": round(dt / steps * 1e3, 3), "scaling": wl.scaling, "config": wl.config()}
     extra = wl.after_timed() if hasattr(wl, "after_timed") else {}
     wl.close()          # the end-to-end pass below brings its own device state
@@ -912,10 +913,13 @@ def main():
     if args.also and args.workload == "glz1080":
         also = {}
         half = max(2, args.steps // 2)
-        mj, p, _ = measure(MjpegWorkload, gpu, dist, args, geo, half, 1)
+        # a step of the MJPEG workloads lasts under a millisecond and two batches are kept in
+        # flight: over three steps the figure would be the pipeline's filling and draining
+        msteps = half if args.sim else max(half, 50)
+        mj, p, _ = measure(MjpegWorkload, gpu, dist, args, geo, msteps, 3)
         also["mjpeg2160"] = p
         for key, dct, q in (("mjpeg2160_islow85", 0, 85), ("mjpeg2160_ifast80", 1, 80)):
-            w2, p2, _ = measure(MjpegWorkload, gpu, dist, args, geo, half, 1, e2e=False, dct=dct, quality=q,
+            w2, p2, _ = measure(MjpegWorkload, gpu, dist, args, geo, msteps, 3, e2e=False, dct=dct, quality=q,
                                 shared=mj)
             also[key] = p2
         if dist.rank == 0:
