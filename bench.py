@@ -51,7 +51,12 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="glz1080", choices=WORKLOADS)
-    ap.add_argument("--sessions", type=int, default=3072, help="GLZ display sessions per GPU")
+    ap.add_argument("--sessions", type=int, default=2880,
+                    help="GLZ display sessions per GPU (2880 x 78 MiB of window state + the input pool "
+                         "fit a fresh 288 GB device; 3072 do not)")
+    ap.add_argument("--flights", type=int, default=2, choices=(1, 2, 3, 4),
+                    help="GLZ batches kept in flight: with 2 the sessions' two halves are submitted "
+                         "alternately, each while the other still runs")
     ap.add_argument("--frames", type=int, default=64,
                     help="MJPEG frames (= streams) per step per GPU; 64 x 4K are 51 rounds of workgroups "
                          "on the GPU's 1024 slots (16 are 12.7 rounds: 10 %% more time per frame)")
@@ -123,14 +128,48 @@ def sha(a):
     return hashlib.sha256(bytes(a)).hexdigest()
 
 
-def roofline_of(kernel, alg_bytes, launches, ms, traffic=None, **extra):
+def roofline_of(kernel, alg_bytes, launches, ms, traffic=None, union_ms=None, **extra):
+    """alg_bytes: algorithmic bytes of ONE launch.  With union_ms (launches of two batches in flight
+    overlap on the device) the achieved rate is all launches' bytes over the time at least one of
+    them was running, not bytes per launch over a launch's duration -- each of two overlapping
+    launches has half the GPU, and its own duration says nothing about the kernel."""
     avg_s = ms / launches / 1e3
-    ach = alg_bytes / avg_s / 1e9
+    overlapped = union_ms is not None and union_ms < 0.98 * ms
+    ach = (alg_bytes * launches / (union_ms / 1e3) if overlapped else alg_bytes / avg_s) / 1e9
     r = {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS,
          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": traffic,
          "avg_launch_ms": round(ms / launches, 3), "algorithmic_bytes_per_launch": int(alg_bytes)}
+    if overlapped:
+        r["launches_overlap"] = {"launches": int(launches), "sum_of_durations_ms": round(ms, 3),
+                                 "union_of_intervals_ms": round(union_ms, 3),
+                                 "how": "achieved = launches x algorithmic_bytes_per_launch / union of the "
+                                        "launches' [start, stop] intervals (HIP events on each launch's own "
+                                        "stream); avg_launch_ms is the plain mean duration, as rocprofv3 shows it"}
     r.update(extra)
     return r
+
+
+def usable_cores():
+    """(cores this process may use, what limits them): the box's CPU share, not the machine's core
+    count -- os.cpu_count() shows every core of the host, a GPU box gives one GPU's share of them"""
+    n, why = os.cpu_count() or 1, "os.cpu_count()"
+    try:
+        a = len(os.sched_getaffinity(0))
+        if a < n:
+            n, why = a, "sched_getaffinity"
+    except (AttributeError, OSError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max" and int(quota) // int(period) >= 1 and int(quota) // int(period) < n:
+            n, why = int(quota) // int(period), "cgroup cpu.max"
+    except (OSError, ValueError):
+        pass
+    share = os.environ.get("OMP_NUM_THREADS", "")
+    if share.isdigit() and 0 < int(share) < n:
+        n, why = int(share), "OMP_NUM_THREADS (the box's CPU share per GPU)"
+    return n, why
 
 
 def timed_threads(nthreads, work):
@@ -201,10 +240,18 @@ class GlzWorkload:
         self.dicts = [B.GlzDictionary(gpu, geo.window, 1) for _ in range(self.S)]
         self.encs = [B.GlzEncoder(gpu, d, 0) for d in self.dicts]
         self.outs = [gpu.malloc(self.cap) for _ in range(self.S)]
-        # the job array is built once; a step only swaps in every session's next frame
-        self.plan = B.GlzBatchPlan(gpu, [self.job(s, 0) for s in range(self.S)])
-        self.step_ptrs = [np.array([self.dev_frames[s % pool][k] for s in range(self.S)], dtype=np.uint64)
-                          for k in range(self.nframes)]
+        # the job arrays are built once; a step only swaps in every session's next frame.  With
+        # two flights the sessions' halves are two batches over disjoint dictionaries: half A's
+        # frame k+1 is submitted while half B's frame k still runs, so the workgroups of one
+        # fill the slots the other's fast sessions have left
+        nfl = max(1, min(getattr(args, "flights", 1), self.S))
+        cut = [self.S * a // nfl for a in range(nfl + 1)]
+        self.halves = [list(range(cut[a], cut[a + 1])) for a in range(nfl)]
+        self.plans = [B.GlzBatchPlan(gpu, [self.job(s, 0) for s in half]) for half in self.halves]
+        self.step_ptrs = [[np.array([self.dev_frames[s % pool][k] for s in half], dtype=np.uint64)
+                           for half in self.halves] for k in range(self.nframes)]
+        self.sizes = {}                 # frame number -> compressed sizes of all sessions
+        self.pending = []               # (half, frame number) in submission order
         self.setup_s = time.time() - t0
         self.k = 0
         self.host_us = []
@@ -220,19 +267,44 @@ class GlzWorkload:
                     stride=self.W * 4, chunks=[self.dev_frames[s % self.pool][k]], chunk_rows=[self.H],
                     out=self.outs[s], out_capacity=self.cap)
 
+    def _finish_oldest(self):
+        a, k = self.pending.pop(0)
+        got = self.plans[a].finish()
+        self.sizes.setdefault(k, self.np.zeros(self.S, dtype=self.np.int32))[self.halves[a]] = got
+        self.host_us[-1] += self.gpu.L.spice_gpu_glz_last_batch_host_ns() / 1e3
+        self.last_sizes = self.sizes[k]
+        return int(got.sum(dtype=self.np.int64))
+
     def step(self):
-        sizes = self.plan.run(self.step_ptrs[self.k])
+        """every session's next frame: each half's previous batch is completed (its sessions'
+        last frames must be out before their next ones go in) and its next one submitted"""
+        got = 0
+        self.host_us.append(0.0)
+        for a in range(len(self.plans)):
+            if any(p[0] == a for p in self.pending):
+                got += self._finish_oldest()          # the oldest batch in flight is this half's
+            self.plans[a].submit(self.step_ptrs[self.k][a])
+            self.pending.append((a, self.k))
         self.k += 1
-        self.host_us.append(self.gpu.L.spice_gpu_glz_last_batch_host_ns() / 1e3)
-        self.last_sizes = sizes
-        return int(sizes.sum(dtype=self.np.int64))
+        return got
+
+    def flush(self):
+        got = 0
+        self.host_us.append(0.0)
+        while self.pending:
+            got += self._finish_oldest()
+        self.host_us.pop()
+        return got
 
     def config(self):
         return {"workload": "glz1080: 1920x1080 RGB32 desktop-like frames, GLZ, one 16 Mi-pixel "
                             "dictionary window per session (BASELINE configs[1])",
                 "sessions_per_gpu": self.S, "sessions_requested": self.args.sessions,
                 "frames_per_session": self.args.steps,
-                "distinct_sequences_per_gpu": self.pool, "out_buffer_bytes_per_session": self.cap,
+                "distinct_sequences_per_gpu": self.pool,
+                "input_frames_shared_by_sessions": round(self.S / self.pool, 1),
+                "batches_in_flight": len(self.plans),
+                "out_buffer_bytes_per_session": self.cap,
                 "parallelism": "session-sharded"}
 
     def roofline(self, times, steps, out_bytes_timed):
@@ -242,10 +314,13 @@ class GlzWorkload:
         # dominant kernel: the parse.  Per launch it must read every pixel of
         # the new images (4 B/px) and write the compressed streams; hash-table
         # and reference traffic is not counted.
-        alg = self.S * self.W * self.H * 4 + out_bytes_timed / max(1, steps)
+        alg = (self.S * self.W * self.H * 4 * steps + out_bytes_timed) / launches
         r = roofline_of("glz_parse_kernel", alg, launches, ms,
+                        union_ms=getattr(self, "unions", {}).get("glz_parse_kernel"),
                         traffic=pmc_traffic(self.name, sessions_per_gpu=self.S,
-                                            distinct_sequences_per_gpu=self.pool))
+                                            distinct_sequences_per_gpu=self.pool,
+                                            batches_in_flight=len(self.plans)),
+                        sessions_per_launch=round(self.S * steps / launches, 1))
         cl, cms = times.get("glz_copy_kernel", (0, 0.0))
         if cl:
             calg = self.S * self.W * self.H * 8
@@ -271,6 +346,7 @@ class GlzWorkload:
         if not self.verify_seqs:          # --verify 0: nothing beyond the timed launches (profiling runs)
             return extra
         self.step()
+        self.flush()
         nver = 0
         for p in self.verify_seqs:
             od = O.GlzDict(self.geo.window, 1)
@@ -346,10 +422,12 @@ class GlzWorkload:
         from oracle import oracle as O
         from spice_amd import frames
         W, H = self.W, self.H
-        threads = max(1, min(16, os.cpu_count() or 1))
+        cores, why = usable_cores()
+        threads = max(1, min(self.S, cores))     # the reference's model: one worker thread per session
         nfr = 64
+        nseq = min(threads, 16)                  # sequences are shared beyond 16 threads (530 MB each)
         seqs = []
-        for t in range(threads):
+        for t in range(nseq):
             seq = frames.DesktopSequence(W, H, seed=5000 + t)
             seqs.append([seq.next().reshape(H, -1) for _ in range(nfr)])
         O.lib()
@@ -360,28 +438,33 @@ class GlzWorkload:
 
             def work(t):
                 for _ in range(passes):
-                    for f in seqs[t]:
+                    for f in seqs[t % nseq]:
                         c0 = time.thread_time()
                         dicts[t].encode(O.TYPE_RGB32, W, H, W * 4, [f])
                         per[t].append(time.thread_time() - c0)
 
             wall, _ = timed_threads(nthreads, work)
+            for d in dicts:
+                d.close()
             enc = [x for p in per for x in p]
             return wall, enc
 
         wall1, enc1 = run(1, 3)                      # one session alone on one core
         walln, encn = run(threads, 4)                # about 20 s of CPU work in all
         px = W * H
+        per_core_busy = len(encn) * px / sum(encn) / 1e6
         return {"value": round(threads * 4 * nfr * px / walln / 1e6, 1), "unit": "Mpixels/s",
-                "cores": threads, "kind": "port",
+                "cores": threads, "host_cores": os.cpu_count(), "usable_cores": cores,
+                "usable_cores_limited_by": why, "kind": "port",
                 "one_core": {"value": round(len(enc1) * px / sum(enc1) / 1e6, 1), "unit": "Mpixels/s",
                              "frame_ms": {"min": round(min(enc1) * 1e3, 2), "max": round(max(enc1) * 1e3, 2),
                                           "mean": round(sum(enc1) / len(enc1) * 1e3, 2)}},
-                "per_core_when_all_busy": round(len(encn) * px / sum(encn) * 1.0 / 1e6, 1),
+                "per_core_when_all_busy": round(per_core_busy, 1),
                 "timer": "CLOCK_THREAD_CPUTIME_ID per encode",
                 "sample": "%d sessions x %d 1920x1080 desktop frames through the CPU oracle "
-                          "(oracle/glz_oracle.c), one thread per session, %.1f s wall; before it one "
-                          "session alone, %d frames, %.1f s" % (threads, 4 * nfr, walln, 3 * nfr, wall1)}
+                          "(oracle/glz_oracle.c), one thread per session = min(sessions, usable cores), "
+                          "%.1f s wall; before it one session alone, %d frames, %.1f s"
+                          % (threads, 4 * nfr, walln, 3 * nfr, wall1)}
 
     def close(self):
         for e in self.encs:
@@ -446,13 +529,23 @@ class MjpegWorkload:
         self.dct, self.quality = dct, quality
         self.W, self.H = geo.w2160, geo.h2160
         self.F = args.frames
-        pool = max(1, min(8, self.F))
+        # every frame of a step is a buffer of its own with content of its own: 64 x 33 MB are
+        # eight times the 256 MiB Infinity Cache, so what the strip kernel reads comes from HBM
+        pool = max(1, self.F)
         t0 = time.time()
         if shared is not None:                   # another quality over the same frames
             self.host_frames, self.dev_frames, self.owns = shared.host_frames, shared.dev_frames, False
         else:
-            seq = frames.VideoSequence(self.W, self.H, seed=7 + dist.rank)
-            self.host_frames = [seq.next() for _ in range(pool)]
+            def make(f):                         # frame f of the stream seeded for it
+                seq = frames.VideoSequence(self.W, self.H, seed=7 + 1000 * dist.rank + f)
+                seq.k = f
+                return seq.next()
+            if pool > 4 and not args.sim:
+                from concurrent.futures import ThreadPoolExecutor
+                with ThreadPoolExecutor(max(1, min(8, usable_cores()[0]))) as ex:
+                    self.host_frames = list(ex.map(make, range(pool)))
+            else:
+                self.host_frames = [make(f) for f in range(pool)]
             self.dev_frames = [gpu.to_device(f) for f in self.host_frames]
             self.owns = True
         self.pool = len(self.dev_frames)
@@ -582,7 +675,8 @@ class MjpegWorkload:
         oracle's restatement of it; one thread per stream, every frame timed with the thread's
         CPU clock."""
         from oracle import oracle as O
-        threads = max(1, min(16, os.cpu_count() or 1))
+        cores, why = usable_cores()
+        threads = max(1, min(self.F, cores))     # one thread per stream
         use_ref = O.ref() is not None
         W, H = self.W, self.H
         px = [f.reshape(H, -1) for f in self.host_frames]
@@ -609,9 +703,11 @@ class MjpegWorkload:
         wall1, enc1 = run(1, 4)
         walln, encn = run(threads, frames_per_thread)
         return {"value": round(threads * frames_per_thread * W * H / walln / 1e6, 1),
-                "unit": "Mpixels/s", "cores": threads, "kind": "reference" if use_ref else "port",
+                "unit": "Mpixels/s", "cores": threads, "host_cores": os.cpu_count(), "usable_cores": cores,
+                "usable_cores_limited_by": why, "kind": "reference" if use_ref else "port",
                 "one_core": {"value": round(len(enc1) * W * H / sum(enc1) / 1e6, 1), "unit": "Mpixels/s",
                              "frame_ms": round(sum(enc1) / len(enc1) * 1e3, 1)},
+                "per_core_when_all_busy": round(len(encn) * W * H / sum(encn) / 1e6, 1),
                 "timer": "CLOCK_THREAD_CPUTIME_ID per frame",
                 "sample": "%d threads x %d 3840x2160 frames through %s, %.1f s wall; before it one "
                           "thread alone, 4 frames"
@@ -825,6 +921,7 @@ def run_workload(wl, gpu, dist, steps, warmup):
     dt = time.perf_counter() - t0
     gpu.L.spice_gpu_timing_enable(0)
     times = gpu.kernel_times()
+    wl.unions = gpu.kernel_union_ms()
     dt_max = dist.max(dt)
     total_units = dist.sum(float(wl.units_per_step * steps))
     return dt_max, total_units, out_bytes, times
@@ -859,6 +956,10 @@ def measure(cls, gpu, dist, args, geo, steps, warmup, e2e=True, cpu=True, **kw):
             part["end_to_end"] = wl.end_to_end()
         if cpu and not args.no_cpu_baseline and hasattr(wl, "cpu_baseline"):
             part["cpu_baseline"] = wl.cpu_baseline()
+            busy = part["cpu_baseline"].get("per_core_when_all_busy")
+            if busy:
+                # how many of the host's cores, all busy, code what this GPU codes
+                part["cpu_baseline"]["gpu_equals_cores"] = round(part["value"] / dist.world / busy, 1)
     return wl, part, (dt, units, out_bytes, times)
 
 

@@ -376,8 +376,9 @@ int spice_gpu_jpeg_finish(SpiceGpuJpegJob *jobs, int njobs);
 
 /* One frame, like a spice_gpu_jpeg_encode_batch of one job, but without any
  * allocation: no counterpart in the reference; it is for callers that cannot
- * allocate device memory where they call from (code under HIP graph capture,
- * tight serving loops, harnesses that forbid it).  The kernels' scratch (the
+ * allocate device memory where they call from (tight serving loops, harnesses
+ * that forbid it; it waits for its result, so it is not for code under HIP graph
+ * capture).  The kernels' scratch (the
  * strips' Huffman bits, their counts and offsets, the unstuffed scan, the job
  * record) lives in an 18 MB array inside the library's code object, one copy per
  * GPU, held until the process ends.  Limits: at most 1024 strips of 10 MCUs
@@ -490,13 +491,17 @@ void spice_gpu_get_stats(int codec, SpiceGpuCodecStats *out);
 void spice_gpu_reset_stats(void);
 
 /* Kernel timing (no counterpart in the reference): when enabled, every kernel
- * the library launches is bracketed by HIP events on the library's stream, and
- * the accumulated device time per kernel name can be read back after the
- * stream has been synchronised. */
+ * the library launches is bracketed by HIP events on the stream it is launched
+ * on, and the accumulated device time per kernel name can be read back once the
+ * batches have been finished.  total_ms adds the launches' durations up;
+ * union_ms is the length of the union of their intervals, which is what the
+ * device spent on the kernel when launches of two batches in flight overlap
+ * (equal to total_ms when they do not). */
 typedef struct SpiceGpuKernelTime {
     char name[48];
     uint64_t launches;
     double total_ms;
+    double union_ms;
 } SpiceGpuKernelTime;
 void spice_gpu_timing_enable(int on);
 void spice_gpu_timing_reset(void);

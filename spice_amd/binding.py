@@ -91,7 +91,8 @@ class SpiceGpuGlzDictInfo(C.Structure):
 
 
 class SpiceGpuKernelTime(C.Structure):
-    _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double)]
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double),
+                ("union_ms", C.c_double)]
 
 
 class MJpegEncoderStats(C.Structure):
@@ -269,6 +270,13 @@ class SpiceGpu:
         buf = (SpiceGpuKernelTime * 32)()
         n = self.L.spice_gpu_timing_read(buf, 32)
         return {buf[k].name.decode(): (buf[k].launches, buf[k].total_ms) for k in range(n)}
+
+    def kernel_union_ms(self):
+        """{kernel name: device ms covered by at least one launch of it} since the last timing
+        reset: launches of two batches in flight overlap, and their durations must not be added."""
+        buf = (SpiceGpuKernelTime * 32)()
+        n = self.L.spice_gpu_timing_read(buf, 32)
+        return {buf[k].name.decode(): buf[k].union_ms for k in range(n)}
 
     # ---- device memory
     def malloc(self, nbytes):
@@ -753,6 +761,21 @@ class GlzBatchPlan:
         if chunk_ptrs is not None:
             self.ptrs[:] = chunk_ptrs
         if self.gpu.L.spice_gpu_glz_encode_batch(self.jobs, self.n) != 0:
+            raise SpiceGpuError("glz batch: " + self.gpu.last_error())
+        return self._sizes.copy()
+
+    # Two batches in flight: two plans over DISJOINT dictionaries, each submitted while the
+    # other still runs (a parse launch lasts as long as its slowest image; the other
+    # batch's workgroups take the places the fast images left).  finish() completes the
+    # calling thread's oldest batch, so plans are finished in the order they were submitted.
+    def submit(self, chunk_ptrs=None):
+        if chunk_ptrs is not None:
+            self.ptrs[:] = chunk_ptrs
+        if self.gpu.L.spice_gpu_glz_submit(self.jobs, self.n) != 0:
+            raise SpiceGpuError("glz batch: " + self.gpu.last_error())
+
+    def finish(self):
+        if self.gpu.L.spice_gpu_glz_finish(self.jobs, self.n) != 0:
             raise SpiceGpuError("glz batch: " + self.gpu.last_error())
         return self._sizes.copy()
 

@@ -79,6 +79,9 @@ struct Dict {
     /* compressed bytes per raw byte of this dictionary's last batch image; 2 until
      * one exists, so that new sessions count as expensive.  Orders a batch. */
     double cost_hint = 2.0;
+    /* a batch between submit and finish has images of this dictionary on the device (set
+     * and cleared with the dictionary locked) */
+    bool in_flight = false;
 
     /* HBM side */
     uint8_t *d_arena = nullptr;
@@ -699,25 +702,56 @@ struct Level {
     size_t results_off = 0;
 };
 
-/* Batch in flight between submit and finish; the device gate is held meanwhile. */
+/* Batch in flight between submit and finish.  There are kFlights slots, each with its
+ * own stream, side stream and staging, so that a caller can keep several batches of
+ * DISJOINT dictionaries on the device: while the slowest sessions of one batch finish
+ * their images, the other batches' workgroups take the places the fast ones left (a
+ * parse launch lasts as long as its slowest image).  A slot belongs to the thread that
+ * submitted into it until that thread's finish. */
 struct Flight {
     std::vector<std::unique_ptr<Level>> levels; /* kept between batches for their buffers */
     size_t nlevels = 0;
     int njobs = 0;
     std::vector<std::unique_lock<std::recursive_mutex>> dict_locks;
+    std::vector<Dict *> dicts;
     std::thread::id owner; /* the thread that submitted: its dictionary locks are its own */
-    bool active = false;
+    bool active = false;   /* claimed; g_fl_mutex guards owner, active, seq, njobs */
+    uint64_t seq = 0;      /* order of submission */
     uint64_t t0 = 0;
-    uint64_t host_ns = 0; /* host time of the last submit + finish, waiting excluded */
+    uint64_t host_ns = 0; /* host time of this batch's submit + finish, waiting excluded */
+    OwnStream main, side;
+    hipEvent_t fork = nullptr, join = nullptr;
 };
-Flight g_flight;
+const int kFlights = 4; /* the device runs the kernels of four hardware queues side by side */
+Flight g_flights[kFlights];
+std::mutex g_fl_mutex;
+std::condition_variable g_fl_cv;
+uint64_t g_fl_seq = 0;
+uint64_t g_last_host_ns = 0;
+
+bool flight_ready(Flight &f)
+{
+    return f.main.ensure() && f.side.ensure() &&
+           (f.fork || check(hipEventCreate(&f.fork), "hipEventCreate")) &&
+           (f.join || check(hipEventCreate(&f.join), "hipEventCreate"));
+}
+
+/* what launch() enqueues on: a stream, and for the copies beside the parse a second one
+ * with the two events that order them (null: everything on the one stream) */
+struct LaunchStreams {
+    hipStream_t s;
+    hipStream_t side;
+    hipEvent_t fork, join;
+};
 
 /* Lays jobs, pools and copy descriptors out in the staging buffer, uploads
  * them and enqueues copy + parse.  copy_on_device: the chunk sources are
  * device pointers (batch path); otherwise the caller has already enqueued
  * host-to-arena copies on the stream. */
-bool launch(Prepared *const *jobs, size_t n, Staging &st, size_t *results_off, bool copy_on_device, hipStream_t s)
+bool launch(Prepared *const *jobs, size_t n, Staging &st, size_t *results_off, bool copy_on_device,
+            const LaunchStreams &ls)
 {
+    hipStream_t s = ls.s;
     size_t off_jobs = 0;
     size_t off_u32 = off_jobs + sizeof(GlzDevJob) * n;
     size_t n_u32 = 0, n_upd = 0, n_copy = 0;
@@ -774,7 +808,7 @@ bool launch(Prepared *const *jobs, size_t n, Staging &st, size_t *results_off, b
     /* When every image of the batch is parsed from its caller's buffer, the copies
      * into the arenas run on the side stream beside the parse; stream() waits
      * for them at the end, so whoever synchronises it has both. */
-    bool beside = copy_on_device && n_copy != 0;
+    bool beside = copy_on_device && n_copy != 0 && ls.side != nullptr;
     for (size_t j = 0; j < n; j++) {
         beside = beside && jobs[j]->dev.own_src != nullptr;
     }
@@ -784,7 +818,7 @@ bool launch(Prepared *const *jobs, size_t n, Staging &st, size_t *results_off, b
     if (copy_on_device && n_copy && !beside) {
         glz_launch_copy((const GlzCopyDesc *)(st.dev + off_copy), (int)n_copy, blocks, s);
     }
-    if (beside && !check(hipEventRecord(fork_event(), s), "event")) {
+    if (beside && !check(hipEventRecord(ls.fork, s), "event")) {
         return false;
     }
     unsigned type_mask = 0;
@@ -797,12 +831,12 @@ bool launch(Prepared *const *jobs, size_t n, Staging &st, size_t *results_off, b
     if (beside) {
         /* after the parse, so that the parse's workgroups take their places first
          * and the copy fills what is left of the CUs */
-        hipStream_t cs = side_stream();
-        if (!check(hipStreamWaitEvent(cs, fork_event(), 0), "wait event")) {
+        hipStream_t cs = ls.side;
+        if (!check(hipStreamWaitEvent(cs, ls.fork, 0), "wait event")) {
             return false;
         }
         glz_launch_copy((const GlzCopyDesc *)(st.dev + off_copy), (int)n_copy, blocks, cs);
-        if (!check(hipEventRecord(join_event(), cs), "event")) {
+        if (!check(hipEventRecord(ls.join, cs), "event")) {
             return false;
         }
     }
@@ -813,7 +847,7 @@ bool launch(Prepared *const *jobs, size_t n, Staging &st, size_t *results_off, b
                               hipMemcpyDeviceToHost, s), "download results")) {
         return false;
     }
-    if (beside && !check(hipStreamWaitEvent(s, join_event(), 0), "wait event")) {
+    if (beside && !check(hipStreamWaitEvent(s, ls.join, 0), "wait event")) {
         return false;
     }
     *results_off = off_res;
@@ -876,9 +910,12 @@ bool combiner_run(Encoder *enc, Prepared *job, int32_t *size)
             c.cv.wait(lk);
             continue;
         }
-        /* lead this round: give the callers that are on their way a moment */
+        /* lead this round: give the callers whose rows are already on their way to the
+         * device a moment (a caller counts itself in only after it has enqueued its upload,
+         * so what is waited for is the rest of a copy, never another caller's allocations
+         * or window bookkeeping) */
         c.leader_active = true;
-        const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(3000);
+        const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(500);
         while (c.entering > 0 && c.cv.wait_until(lk, until) != std::cv_status::timeout) {
         }
         std::vector<Waiting *> round;
@@ -889,7 +926,8 @@ bool combiner_run(Encoder *enc, Prepared *job, int32_t *size)
             ptrs.push_back(w->job);
         }
         size_t res_off = 0;
-        bool ok = launch(ptrs.data(), ptrs.size(), enc->staging, &res_off, false, enc->st);
+        bool ok = launch(ptrs.data(), ptrs.size(), enc->staging, &res_off, false,
+                         LaunchStreams{enc->st, nullptr, nullptr, nullptr});
         ok = check(hipStreamSynchronize(enc->st), "glz sync") && ok;
         const int32_t *res = (const int32_t *)(enc->staging.host + res_off);
         lk.lock();
@@ -1180,17 +1218,11 @@ int glz_encode(GlzEncoderContext *opaque_encoder, LzImageType type, int width, i
      * stream and buffers, so encoders of different dictionaries do not wait for
      * each other (a batch in flight holds the locks of its dictionaries) */
     std::lock_guard<std::recursive_mutex> dict_lock(d->lock);
-    /* from here until the job is queued, a round's leader waits for this caller */
-    struct Entering {
-        bool counted = true;
-        Entering() { combiner_enter(); }
-        ~Entering()
-        {
-            if (counted) {
-                combiner_leave();
-            }
-        }
-    } entering;
+    if (d->in_flight) {
+        /* only the thread that holds the lock recursively gets here: its own batch */
+        usr_error(enc->usr, "this thread has a batch in flight on the dictionary\n");
+        return 0;
+    }
 
     size_t bound = spice_gpu_glz_out_bound(type, width, height);
     if (!enc->out.reserve(bound) || !enc->bounce.reserve(bound)) {
@@ -1213,6 +1245,17 @@ int glz_encode(GlzEncoderContext *opaque_encoder, LzImageType type, int width, i
     for (const GlzCopyDesc &c : jobs[0].copies) {
         ok = ok && check(hipMemcpyAsync(c.dst, c.src, c.bytes, hipMemcpyHostToDevice, s), "upload rows");
     }
+    /* from here until the job is queued, a round's leader waits for this caller (briefly) */
+    struct Entering {
+        bool counted = true;
+        Entering() { combiner_enter(); }
+        ~Entering()
+        {
+            if (counted) {
+                combiner_leave();
+            }
+        }
+    } entering;
     ok = ok && check(hipStreamSynchronize(s), "upload rows");
     int32_t size = 0;
     if (ok) {
@@ -1226,6 +1269,12 @@ int glz_encode(GlzEncoderContext *opaque_encoder, LzImageType type, int width, i
     }
     if (!ok) {
         hipStreamSynchronize(s); /* nothing of this image may still be running */
+        /* the segment updates prepare() took off the dictionary's list may not have reached
+         * the device: they go back on it, or the device's table would keep evicted segments
+         * alive */
+        for (const GlzDevSegUpdate &u : jobs[0].updates) {
+            d->dirty.push_back(u.index);
+        }
     }
     if (!ok || size <= 0) {
         kill_image(d, jobs[0].image);
@@ -1328,16 +1377,62 @@ int spice_gpu_glz_submit(SpiceGpuGlzJob *jobs, int njobs)
         level_of[(size_t)j] = seen[k]++;
         nlevels = seen[k] > nlevels ? seen[k] : nlevels;
     }
-    /* lock order everywhere: dictionaries, then the device */
+    /* lock order everywhere: dictionaries, then a flight slot */
     std::vector<std::unique_lock<std::recursive_mutex>> dict_locks;
     dict_locks.reserve(distinct.size());
     for (Dict *d : distinct) {
         dict_locks.emplace_back(d->lock);
     }
-    if (!device_gate().acquire("glz batch")) {
+    for (Dict *d : distinct) {
+        if (d->in_flight) {
+            /* the locks are recursive: only this thread's own earlier batch gets here */
+            set_error("glz batch: a dictionary of this batch is in another batch in flight "
+                      "(two batches in flight must use disjoint dictionaries)");
+            return -1;
+        }
+    }
+    /* a free flight slot; a thread may hold both, a third submit is refused, and while
+     * other threads hold them this one waits for a finish */
+    Flight *fp = nullptr;
+    {
+        std::unique_lock<std::mutex> lk(g_fl_mutex);
+        const std::thread::id me = std::this_thread::get_id();
+        for (;;) {
+            int mine = 0;
+            fp = nullptr;
+            for (Flight &c : g_flights) {
+                if (!c.active) {
+                    fp = fp ? fp : &c;
+                } else if (c.owner == me) {
+                    mine++;
+                }
+            }
+            if (mine >= kFlights) {
+                set_error("glz batch: this thread has %d batches in flight already (finish one first)", mine);
+                return -1;
+            }
+            if (fp) {
+                break;
+            }
+            g_fl_cv.wait(lk);
+        }
+        fp->active = true;
+        fp->owner = me;
+        fp->seq = ++g_fl_seq;
+        fp->njobs = njobs;
+    }
+    Flight &f = *fp;
+    auto give_back = [&f]() {
+        std::lock_guard<std::mutex> lk(g_fl_mutex);
+        f.active = false;
+        f.nlevels = 0;
+        g_fl_cv.notify_all();
+    };
+    if (!flight_ready(f)) {
+        give_back();
         return -1;
     }
-    Flight &f = g_flight;
+    const LaunchStreams ls{f.main.st, f.side.st, f.fork, f.join};
     while (f.levels.size() < nlevels) {
         f.levels.emplace_back(new Level());
     }
@@ -1348,7 +1443,6 @@ int spice_gpu_glz_submit(SpiceGpuGlzJob *jobs, int njobs)
         f.levels[level_of[(size_t)j]]->idx.push_back(j);
     }
     f.nlevels = nlevels;
-    f.njobs = njobs;
     f.t0 = t_in;
 
     bool ok = true;
@@ -1370,7 +1464,7 @@ int spice_gpu_glz_submit(SpiceGpuGlzJob *jobs, int njobs)
             }
             const char *err = prepare((Encoder *)job.encoder, job.type, job.width, job.height,
                                       job.top_down, job.stride, chunks, job.usr_context,
-                                      (uint8_t *)job.out, job.out_capacity, true, stream(), &p);
+                                      (uint8_t *)job.out, job.out_capacity, true, ls.s, &p);
             if (err) {
                 set_error("glz batch job %d: %s", j, err);
                 p.reset();
@@ -1384,7 +1478,7 @@ int spice_gpu_glz_submit(SpiceGpuGlzJob *jobs, int njobs)
             for (size_t k = 0; k < lv.idx.size(); k++) {
                 lv.ptrs[k] = &lv.jobs[k];
             }
-            ok = launch(lv.ptrs.data(), lv.idx.size(), lv.staging, &lv.results_off, true, stream());
+            ok = launch(lv.ptrs.data(), lv.idx.size(), lv.staging, &lv.results_off, true, ls);
             done = lv.idx.size();
         }
         if (ok) {
@@ -1400,7 +1494,7 @@ int spice_gpu_glz_submit(SpiceGpuGlzJob *jobs, int njobs)
             }
             /* images of the levels already enqueued: their streams are never
              * handed out, so they die too */
-            hipStreamSynchronize(stream());
+            hipStreamSynchronize(ls.s);
             for (size_t e = 0; e < l; e++) {
                 Level &el = *f.levels[e];
                 for (size_t k = 0; k < el.idx.size(); k++) {
@@ -1413,31 +1507,48 @@ int spice_gpu_glz_submit(SpiceGpuGlzJob *jobs, int njobs)
         for (int j = 0; j < njobs; j++) {
             jobs[j].dict_image = nullptr;
         }
-        f.nlevels = 0;
-        device_gate().release();
+        give_back();
         return -1;
     }
+    for (Dict *d : distinct) {
+        d->in_flight = true;
+    }
+    f.dicts = distinct;
     f.dict_locks = std::move(dict_locks);
-    f.owner = std::this_thread::get_id();
-    f.active = true;
     f.host_ns = now_ns() - t_in;
     return 0;
 }
 
+/* Completes the calling thread's OLDEST batch in flight: jobs / njobs are that batch's. */
 int spice_gpu_glz_finish(SpiceGpuGlzJob *jobs, int njobs)
 {
-    Flight &f = g_flight;
-    if (!f.active || njobs != f.njobs) {
-        set_error("glz batch: finish without a matching submit");
-        return -1;
+    Flight *fp = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_fl_mutex);
+        const std::thread::id me = std::this_thread::get_id();
+        bool others = false;
+        for (Flight &c : g_flights) {
+            if (c.active && c.owner == me) {
+                fp = (!fp || c.seq < fp->seq) ? &c : fp;
+            } else if (c.active) {
+                others = true;
+            }
+        }
+        if (!fp) {
+            /* a batch holds its dictionaries' locks, and a lock is released by the thread
+             * that took it; another thread's batch stays in flight for its own thread */
+            set_error(others ? "glz batch: finish must be called by the thread that submitted the batch"
+                             : "glz batch: finish without a matching submit");
+            return -1;
+        }
+        if (njobs != fp->njobs) {
+            set_error("glz batch: finish does not match this thread's oldest batch in flight (%d jobs, not %d)",
+                      fp->njobs, njobs);
+            return -1;
+        }
     }
-    if (f.owner != std::this_thread::get_id()) {
-        /* the batch holds its dictionaries' locks, and a lock is released by the
-         * thread that took it; the batch stays in flight for its own thread */
-        set_error("glz batch: finish must be called by the thread that submitted the batch");
-        return -1;
-    }
-    bool ok = check(hipStreamSynchronize(stream()), "glz batch sync");
+    Flight &f = *fp;
+    bool ok = check(hipStreamSynchronize(f.main.st), "glz batch sync");
     const uint64_t t_sync = now_ns();
     int rc = ok ? 0 : -1;
     uint64_t dt = t_sync - f.t0;
@@ -1463,17 +1574,26 @@ int spice_gpu_glz_finish(SpiceGpuGlzJob *jobs, int njobs)
             }
         }
     }
+    for (Dict *d : f.dicts) {
+        d->in_flight = false;
+    }
+    f.dicts.clear();
     f.dict_locks.clear();
-    f.nlevels = 0;
-    f.active = false;
     f.host_ns += now_ns() - t_sync;
-    device_gate().release();
+    {
+        std::lock_guard<std::mutex> lk(g_fl_mutex);
+        g_last_host_ns = f.host_ns;
+        f.nlevels = 0;
+        f.active = false;
+        g_fl_cv.notify_all();
+    }
     return rc;
 }
 
 uint64_t spice_gpu_glz_last_batch_host_ns(void)
 {
-    return g_flight.host_ns;
+    std::lock_guard<std::mutex> lk(g_fl_mutex);
+    return g_last_host_ns;
 }
 
 int spice_gpu_glz_encode_batch(SpiceGpuGlzJob *jobs, int njobs)

@@ -11,7 +11,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <condition_variable>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "jpeg_device.h"
@@ -304,32 +306,39 @@ void jpeg_huff_words(uint32_t *h)
 
 namespace {
 
-/* Library-owned device scratch for one batch (guarded by the device gate). */
+/* Library-owned device scratch and stream of one batch. */
 struct JpegFlight {
     Staging staging;      /* JpegDevJob array + results */
     DevBuffer scratch;
     uint32_t *d_huff = nullptr;
     size_t results_off = 0;
     int njobs = 0;
-    bool active = false; /* between submit and finish; the gate is held meanwhile */
+    bool active = false;  /* claimed by a submit, until its finish; g_jf_mutex guards it */
+    std::thread::id owner;
+    uint64_t seq = 0;     /* order of submission */
     uint64_t t0 = 0;
     uint64_t raw_bytes = 0;
     int stat_codec = SPICE_GPU_STAT_MJPEG;
     hipEvent_t strips_done = nullptr; /* recorded behind this flight's strip kernels */
+    OwnStream own;
 };
 /* Two batches may be in flight, the second submitted while the first still runs: each has
  * its own stream, job upload area and scratch, so the kernels of one overlap the host's
- * work for, and the short bit-stream kernels of, the other.  g_jf is slot 0, which the
- * synchronous entry points use as well.  All of it belongs to the thread that holds the
- * device gate. */
-JpegFlight g_jfs[2];
-JpegFlight &g_jf = g_jfs[0];
-int g_jf_head = 0;   /* the older active flight */
-int g_jf_active = 0; /* 0..2 */
+ * work for, and the short bit-stream kernels of, the other.  A slot belongs to the thread
+ * whose submit claimed it until that thread's finish; claiming, enqueuing and releasing
+ * happen under g_jf_mutex, which no call keeps when it returns -- a thread that pipelines
+ * batches holds up nobody but a third batch.  The synchronous entry points have a flight
+ * of their own (g_jf_sync) on the library's stream(), used under the device gate. */
+const int kJpegFlights = 2;
+JpegFlight g_jfs[kJpegFlights];
+JpegFlight g_jf_sync;
+std::mutex g_jf_mutex;
+std::condition_variable g_jf_cv;
+uint64_t g_jf_seq = 0;
 
 hipStream_t flight_stream(const JpegFlight &f)
 {
-    return &f == &g_jfs[1] ? side_stream() : stream();
+    return &f == &g_jf_sync ? stream() : f.own.st;
 }
 
 bool ensure_huff(JpegFlight &f)
@@ -350,7 +359,8 @@ size_t align256(size_t v)
     return (v + 255) & ~(size_t)255;
 }
 
-/* Enqueues a batch.  Caller holds the device gate and has filled jobs[] with fill_job. */
+/* Enqueues a batch into a flight the caller owns (g_jf_mutex held for g_jfs[], the device
+ * gate for g_jf_sync); jobs[] filled with fill_job. */
 bool submit_locked(JpegFlight &f, std::vector<JpegDevJob> &jobs)
 {
     int n = (int)jobs.size();
@@ -403,10 +413,15 @@ bool submit_locked(JpegFlight &f, std::vector<JpegDevJob> &jobs)
         !check(hipEventCreate(&f.strips_done), "hipEventCreate")) {
         return false;
     }
-    /* the other slot's strip kernels first, if it has a batch in flight */
-    JpegFlight &other = g_jfs[&f == &g_jfs[0] ? 1 : 0];
+    /* the other slot's strip kernels first, if it has a batch in flight (two strip kernels
+     * side by side share the CUs, each lasts longer and a per-launch duration says nothing) */
+    hipEvent_t after = nullptr;
+    if (&f != &g_jf_sync) {
+        JpegFlight &other = g_jfs[&f == &g_jfs[0] ? 1 : 0];
+        after = other.active ? other.strips_done : nullptr;
+    }
     jpeg_launch((const JpegDevJob *)f.staging.dev, n, max_groups, any_islow, any_ifast, f.d_huff, s, true,
-                other.active ? other.strips_done : nullptr, f.strips_done);
+                after, f.strips_done);
     if (!check(hipGetLastError(), "jpeg launch")) {
         return false;
     }
@@ -451,10 +466,10 @@ size_t encode_host_frame(HostPath &hp, int format, int width, int height, int qu
     hipStream_t s = stream();
     if (!check(hipMemcpyAsync(hp.d_frame.ptr, hp.frame.ptr, bytes, hipMemcpyHostToDevice, s),
                "upload frame") ||
-        !submit_locked(g_jf, jobs) || !check(hipStreamSynchronize(s), "jpeg sync")) {
+        !submit_locked(g_jf_sync, jobs) || !check(hipStreamSynchronize(s), "jpeg sync")) {
         return 0;
     }
-    int32_t size = *(int32_t *)(g_jf.staging.host + g_jf.results_off);
+    int32_t size = *(int32_t *)(g_jf_sync.staging.host + g_jf_sync.results_off);
     if (size <= 0) {
         set_error("jpeg: output does not fit (%d)", size);
         return 0;
@@ -806,46 +821,68 @@ int spice_gpu_jpeg_submit(SpiceGpuJpegJob *jobs, int njobs)
         }
         raw_bytes += (uint64_t)j.width * (uint64_t)j.height * (uint64_t)format_bpp(j.format);
     }
-    /* The gate stays taken from a thread's first submit until its last finish.  The
-     * thread that holds it for a JPEG batch may submit one more; a third submit, or a
-     * submit while it holds the gate for something else, is refused; a submit from
-     * another thread waits for the finish. */
-    const bool mine = device_gate().held_by_caller();
-    if (mine && (g_jf_active == 0 || g_jf_active == 2)) {
-        set_error(g_jf_active ? "jpeg batch: two batches are in flight already (finish one first)"
-                              : "jpeg batch: this thread has another batch in flight");
-        return -1;
+    /* a free flight slot: a thread may hold both, a third submit is refused, and while
+     * other threads hold them this one waits for a finish */
+    std::unique_lock<std::mutex> lk(g_jf_mutex);
+    const std::thread::id me = std::this_thread::get_id();
+    JpegFlight *fp = nullptr;
+    for (;;) {
+        int mine = 0;
+        fp = nullptr;
+        for (JpegFlight &c : g_jfs) {
+            if (!c.active) {
+                fp = fp ? fp : &c;
+            } else if (c.owner == me) {
+                mine++;
+            }
+        }
+        if (mine >= kJpegFlights) {
+            set_error("jpeg batch: two batches are in flight already (finish one first)");
+            return -1;
+        }
+        if (fp) {
+            break;
+        }
+        g_jf_cv.wait(lk);
     }
-    if (!mine && !device_gate().acquire("jpeg batch")) {
-        return -1;
-    }
-    JpegFlight &f = g_jfs[(g_jf_head + g_jf_active) & 1];
+    JpegFlight &f = *fp;
     f.raw_bytes = raw_bytes;
     f.t0 = now_ns();
-    if (!submit_locked(f, dj)) {
-        hipStreamSynchronize(flight_stream(f));
-        if (g_jf_active == 0) {
-            device_gate().release();
+    if (!f.own.ensure() || !submit_locked(f, dj)) {
+        if (f.own.st) {
+            hipStreamSynchronize(f.own.st);
         }
         return -1;
     }
     f.active = true;
-    g_jf_active++;
+    f.owner = me;
+    f.seq = ++g_jf_seq;
     return 0;
 }
 
-/* Completes the OLDEST batch in flight: jobs / njobs are that batch's. */
+/* Completes the calling thread's OLDEST batch in flight: jobs / njobs are that batch's. */
 int spice_gpu_jpeg_finish(SpiceGpuJpegJob *jobs, int njobs)
 {
-    if (!device_gate().held_by_caller() || g_jf_active == 0) {
-        set_error("jpeg batch: finish without a matching submit");
-        return -1;
+    JpegFlight *fp = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_jf_mutex);
+        const std::thread::id me = std::this_thread::get_id();
+        for (JpegFlight &c : g_jfs) {
+            if (c.active && c.owner == me && (!fp || c.seq < fp->seq)) {
+                fp = &c;
+            }
+        }
+        if (!fp) {
+            set_error("jpeg batch: finish without a matching submit");
+            return -1;
+        }
+        if (njobs != fp->njobs) {
+            set_error("jpeg batch: finish does not match the oldest batch in flight (%d jobs, not %d)",
+                      fp->njobs, njobs);
+            return -1;
+        }
     }
-    JpegFlight &f = g_jfs[g_jf_head];
-    if (!f.active || njobs != f.njobs) {
-        set_error("jpeg batch: finish does not match the oldest batch in flight (%d jobs, not %d)", f.njobs, njobs);
-        return -1;
-    }
+    JpegFlight &f = *fp;
     bool ok = check(hipStreamSynchronize(flight_stream(f)), "jpeg batch sync");
     const int32_t *res = (const int32_t *)(f.staging.host + f.results_off);
     int rc = ok ? 0 : -1;
@@ -865,20 +902,26 @@ int spice_gpu_jpeg_finish(SpiceGpuJpegJob *jobs, int njobs)
                      dt / (uint64_t)njobs);
         }
     }
-    f.active = false;
-    g_jf_head ^= 1;
-    if (--g_jf_active == 0) {
-        g_jf_head = 0;
-        device_gate().release();
+    {
+        std::lock_guard<std::mutex> lk(g_jf_mutex);
+        f.active = false;
+        g_jf_cv.notify_all();
     }
     return rc;
 }
 
 int spice_gpu_jpeg_encode_batch(SpiceGpuJpegJob *jobs, int njobs)
 {
-    if (device_gate().held_by_caller()) {
-        set_error("jpeg batch: this thread has a batch in flight (finish it first)");
-        return -1;
+    {
+        std::lock_guard<std::mutex> lk(g_jf_mutex);
+        const std::thread::id me = std::this_thread::get_id();
+        for (JpegFlight &c : g_jfs) {
+            if (c.active && c.owner == me) {
+                /* finish would complete the older batch, not this one */
+                set_error("jpeg batch: this thread has a batch in flight (finish it first)");
+                return -1;
+            }
+        }
     }
     if (spice_gpu_jpeg_submit(jobs, njobs) != 0) {
         return -1;

@@ -1513,8 +1513,9 @@ void jpeg_launch(const JpegDevJob *jobs, int njobs, int max_groups, bool any_isl
 
 /* ---------------------------------------------------------------------------
  * One frame through the same kernels with no allocation of any kind: for callers
- * that cannot allocate device memory where they call from (code under HIP graph
- * capture, tight serving loops, harnesses that forbid it).  What
+ * that cannot allocate device memory where they call from (tight serving loops,
+ * harnesses that forbid it; the call waits for its result on the stream, so it is
+ * not for code under HIP graph capture).  What
  * spice_gpu_jpeg_encode_batch takes from hipMalloc'ed, growing buffers -- the job
  * record, the Huffman tables, the strips' bit slots, their counts and offsets,
  * the unstuffed scan and the 0xFF counts -- lives in one array of the code
@@ -1560,6 +1561,9 @@ static __device__ __align__(256) uint8_t jpeg_na_scratch[JPEG_NA_BYTES];
 
 /* device address of jpeg_na_scratch on each GPU this process has initialised */
 static uint8_t *g_jpeg_na_ptr[JPEG_NA_MAX_DEVICES];
+/* a pinned host word per GPU, made at set-up, where a call's result lands: a copy into
+ * pageable memory would go through a staging buffer of the runtime's */
+static int32_t *g_jpeg_na_result[JPEG_NA_MAX_DEVICES];
 
 bool jpeg_fill_job(JpegDevJob *j, const void *pixels, int format, int width, int height, long stride,
                    int quality, int dct, void *out, uint32_t out_cap);
@@ -1593,6 +1597,11 @@ bool jpeg_noalloc_setup(int device)
     jpeg_huff_words(h);
     if (!spicegpu::check(hipMemcpy(ptr + JPEG_NA_OFF_HUFF, h, sizeof(h), hipMemcpyHostToDevice),
                          "upload Huffman tables")) {
+        return false;
+    }
+    if (!g_jpeg_na_result[device] &&
+        !spicegpu::check(hipHostMalloc((void **)&g_jpeg_na_result[device], 64, hipHostMallocDefault),
+                         "hipHostMalloc (result word)")) {
         return false;
     }
     g_jpeg_na_ptr[device] = ptr;
@@ -1649,19 +1658,22 @@ extern "C" int spice_gpu_jpeg_encode_noalloc(SpiceGpuJpegJob *job)
     hipLaunchKernelGGL(jpeg_na_put_job, dim3(1), dim3(64), 0, s, dj, (JpegDevJob *)ptr);
     jpeg_launch((const JpegDevJob *)ptr, 1, groups, dj.dct == 0, dj.dct != 0,
                 (const uint32_t *)(ptr + JPEG_NA_OFF_HUFF), s, false, nullptr, nullptr);
-    int32_t size = 0;
+    int32_t *const landing = g_jpeg_na_result[device];
     if (!check(hipGetLastError(), "jpeg launch") ||
-        !check(hipMemcpyAsync(&size, ptr + JPEG_NA_OFF_RESULT, sizeof(size), hipMemcpyDeviceToHost, s),
+        !check(hipMemcpyAsync(landing, ptr + JPEG_NA_OFF_RESULT, sizeof(int32_t), hipMemcpyDeviceToHost, s),
                "read result") ||
         !check(hipStreamSynchronize(s), "jpeg sync")) {
         return -1;
     }
+    const int32_t size = *landing;
     job->out_size = size;
     if (size <= 0) {
         set_error("jpeg (no allocation): output does not fit (%d)", size);
         return -1;
     }
-    stat_add(SPICE_GPU_STAT_MJPEG, (uint64_t)dj.width * (uint64_t)dj.height * 4u, (uint64_t)size,
+    const uint64_t bpp = job->format == SPICE_GPU_BITMAP_FMT_16BIT ? 2u
+                       : (job->format == SPICE_GPU_BITMAP_FMT_24BIT || job->format == JPEG_FMT_RGB24) ? 3u : 4u;
+    stat_add(SPICE_GPU_STAT_MJPEG, (uint64_t)dj.width * (uint64_t)dj.height * bpp, (uint64_t)size,
              now_ns() - t0);
     return 0;
 }

@@ -8,6 +8,7 @@
 #include <string.h>
 #include <time.h>
 
+#include <algorithm>
 #include <condition_variable>
 #include <string>
 #include <thread>
@@ -27,8 +28,7 @@ DeviceGate g_gate;
 std::mutex g_stat_mutex;
 bool g_ready = false;
 int g_device = -1;
-hipStream_t g_stream = nullptr, g_side_stream = nullptr;
-hipEvent_t g_fork = nullptr, g_join = nullptr;
+hipStream_t g_stream = nullptr;
 thread_local char g_error[512] = "";
 SpiceGpuCodecStats g_stats[SPICE_GPU_STAT_COUNT];
 } // namespace
@@ -68,12 +68,6 @@ static bool init_locked(int device)
                             "hipStreamCreate")) {
         return false;
     }
-    if (!g_side_stream && !(check(hipStreamCreateWithFlags(&g_side_stream, hipStreamNonBlocking),
-                                  "hipStreamCreate") &&
-                            check(hipEventCreate(&g_fork), "hipEventCreate") &&
-                            check(hipEventCreate(&g_join), "hipEventCreate"))) {
-        return false;
-    }
     /* the device-resident scratch of the entry point that allocates nothing */
     if (!jpeg_noalloc_setup(device)) {
         return false;
@@ -103,19 +97,9 @@ hipStream_t stream()
     return g_stream;
 }
 
-hipStream_t side_stream()
+bool OwnStream::ensure()
 {
-    return g_side_stream;
-}
-
-hipEvent_t fork_event()
-{
-    return g_fork;
-}
-
-hipEvent_t join_event()
-{
-    return g_join;
+    return st || check(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate");
 }
 
 bool DeviceGate::acquire(const char *who)
@@ -189,6 +173,12 @@ std::vector<std::string> g_time_names;
 std::vector<SpiceGpuKernelTime> g_time_acc;
 std::vector<TimedLaunch> g_time_pending;
 std::vector<hipEvent_t> g_event_pool;
+/* Launches of one kernel on different streams may overlap (two batches in flight); what the
+ * device spent on the kernel is then the union of the launches' intervals, not their sum.
+ * Every collected launch leaves its [begin, end] in milliseconds after g_time_base, an event
+ * recorded when the counters were last reset. */
+hipEvent_t g_time_base = nullptr;
+std::vector<std::vector<std::pair<float, float>>> g_time_spans;
 
 hipEvent_t take_event()
 {
@@ -220,6 +210,12 @@ void timing_collect_locked()
         }
         g_time_acc[(size_t)t.name_id].launches++;
         g_time_acc[(size_t)t.name_id].total_ms += (double)ms;
+        float a_ms = 0.f;
+        if (g_time_base && hipEventElapsedTime(&a_ms, g_time_base, t.a) == hipSuccess) {
+            g_time_spans[(size_t)t.name_id].push_back(std::make_pair(a_ms, a_ms + ms));
+        } else {
+            (void)hipGetLastError();
+        }
         g_event_pool.push_back(t.a);
         g_event_pool.push_back(t.b);
     }
@@ -244,6 +240,7 @@ TimedLaunch &timing_entry_locked(const char *kernel_name, bool closed)
         memset(&t, 0, sizeof(t));
         snprintf(t.name, sizeof(t.name), "%s", kernel_name);
         g_time_acc.push_back(t);
+        g_time_spans.emplace_back();
     }
     TimedLaunch t{id, g_time_next_id, closed, take_event(), take_event()};
     g_time_next_id = (g_time_next_id + 1) & 0x3fffffff;
@@ -395,19 +392,6 @@ void spice_gpu_shutdown(void)
         hipStreamDestroy(g_stream);
         g_stream = nullptr;
     }
-    if (g_side_stream) {
-        hipStreamSynchronize(g_side_stream);
-        hipStreamDestroy(g_side_stream);
-        g_side_stream = nullptr;
-    }
-    if (g_fork) {
-        hipEventDestroy(g_fork);
-        g_fork = nullptr;
-    }
-    if (g_join) {
-        hipEventDestroy(g_join);
-        g_join = nullptr;
-    }
     g_ready = false;
 }
 
@@ -485,6 +469,17 @@ void spice_gpu_timing_reset(void)
     for (SpiceGpuKernelTime &t : g_time_acc) {
         t.launches = 0;
         t.total_ms = 0.0;
+        t.union_ms = 0.0;
+    }
+    for (auto &v : g_time_spans) {
+        v.clear();
+    }
+    if (g_stream) {
+        if (!g_time_base) {
+            hipEventCreate(&g_time_base);
+        }
+        hipEventRecord(g_time_base, g_stream);
+        hipStreamSynchronize(g_stream);
     }
 }
 
@@ -496,9 +491,25 @@ int spice_gpu_timing_read(SpiceGpuKernelTime *out, int max_entries)
     }
     timing_collect_locked();
     int n = 0;
-    for (const SpiceGpuKernelTime &t : g_time_acc) {
+    for (size_t k = 0; k < g_time_acc.size(); k++) {
+        /* length of the union of this kernel's launch intervals */
+        std::vector<std::pair<float, float>> v(g_time_spans[k]);
+        std::sort(v.begin(), v.end());
+        double u = 0.0;
+        float lo = 0.f, hi = -1.f;
+        for (const auto &iv : v) {
+            if (hi < lo || iv.first > hi) {
+                u += hi > lo ? (double)(hi - lo) : 0.0;
+                lo = iv.first;
+                hi = iv.second;
+            } else if (iv.second > hi) {
+                hi = iv.second;
+            }
+        }
+        u += hi > lo ? (double)(hi - lo) : 0.0;
+        g_time_acc[k].union_ms = v.empty() ? g_time_acc[k].total_ms : u;
         if (n < max_entries) {
-            out[n++] = t;
+            out[n++] = g_time_acc[k];
         }
     }
     return n;

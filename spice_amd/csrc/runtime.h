@@ -22,17 +22,18 @@ bool ensure_init();
 /* the device spice_gpu_init selected, or -1 before it ran */
 int current_device();
 hipStream_t stream();
-/* a second stream for work that may run beside stream()'s, and two events to order them */
-hipStream_t side_stream();
-hipEvent_t fork_event();
-hipEvent_t join_event();
 void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
 bool check(hipError_t e, const char *what);
 
-/* Serialises device work issued through the library's single stream.  Unlike a
- * mutex it may be released by another thread than the one that took it (a batch
- * is submitted and finished by two calls), and a thread that asks for it while
- * it holds it itself is told so instead of waiting for ever. */
+/* Serialises the short stretches in which a call enqueues work on the library's own
+ * stream() (dictionary reset, graduality, the synchronous JPEG entry points, the entry
+ * point that allocates nothing).  It is taken and released inside one API call, never
+ * held from one call to the next: batches in flight (spice_gpu_glz_submit /
+ * spice_gpu_jpeg_submit) own a flight slot with a stream of its own instead, so a thread
+ * that pipelines batches keeps no other thread out of the library.  Lock order: a GLZ
+ * dictionary's lock first, then this gate or a flight-slot mutex; never the other way
+ * round.  A thread that asks for the gate while it holds it is told so instead of
+ * waiting for ever. */
 class DeviceGate {
 public:
     /* false (with the error text set) when the calling thread already holds the gate */
@@ -55,6 +56,13 @@ struct GateHold {
     }
     GateHold(const GateHold &) = delete;
     GateHold &operator=(const GateHold &) = delete;
+};
+
+/* A stream (and, on demand, a pair of events) that belongs to one flight slot; made on
+ * first use, kept until the process ends. */
+struct OwnStream {
+    hipStream_t st = nullptr;
+    bool ensure();
 };
 
 void stat_add(int codec, uint64_t orig, uint64_t comp, uint64_t ns);

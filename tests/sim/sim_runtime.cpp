@@ -286,6 +286,12 @@ size_t page_size()
 } // namespace
 
 static std::mutex allocs_mutex; /* worker threads allocate side by side */
+static unsigned long alloc_calls; /* hipMalloc + hipHostMalloc, for tests of entry points that must not allocate */
+extern "C" unsigned long sim_alloc_calls(void)
+{
+    std::lock_guard<std::mutex> lk(allocs_mutex);
+    return alloc_calls;
+}
 
 hipError_t hipMalloc(void **out, size_t n)
 {
@@ -302,6 +308,7 @@ hipError_t hipMalloc(void **out, size_t n)
     char *p = m + pg + pages - body; /* the end of the buffer touches the guard page */
     memset(p, 0xcd, body);
     std::lock_guard<std::mutex> lk(allocs_mutex);
+    alloc_calls++;
     allocs[p] = Alloc{m, len};
     *out = p;
     return hipSuccess;
@@ -324,6 +331,10 @@ hipError_t hipFree(void *p)
 
 hipError_t hipHostMalloc(void **p, size_t n, unsigned)
 {
+    {
+        std::lock_guard<std::mutex> lk(allocs_mutex);
+        alloc_calls++;
+    }
     *p = malloc(n ? n : 1);
     return *p ? hipSuccess : hipErrorOutOfMemory;
 }

@@ -181,12 +181,14 @@ def test_sim_shared_dictionary_batch(sim, oracle):
     run_shared_dictionary(sim, oracle, 96, 40, window=96 * 40 * 6 + 100, nframes=4)
 
 
-def test_sim_failed_batches_leave_windows_usable(sim, oracle):
+def run_failed_batches(sim, oracle, scale=1):
     """a batch that is refused changes nothing; a job whose output does not fit leaves a
     dead image behind (as after remove_image) and the sessions carry on"""
-    specs = [(B.LZ_IMAGE_TYPE_RGB32, 96, 40, "desktop"), (B.LZ_IMAGE_TYPE_RGB32, 64, 32, "noise"),
-             (B.LZ_IMAGE_TYPE_RGB32, 80, 30, "desktop")]
-    sessions = [Session(sim, oracle, *spec, seed=11 + k, window=1 << 14) for k, spec in enumerate(specs)]
+    specs = [(B.LZ_IMAGE_TYPE_RGB32, 96 * scale, 40 * scale, "desktop"),
+             (B.LZ_IMAGE_TYPE_RGB32, 64 * scale, 32 * scale, "noise"),
+             (B.LZ_IMAGE_TYPE_RGB32, 80 * scale, 30 * scale, "desktop")]
+    sessions = [Session(sim, oracle, *spec, seed=11 + k, window=(1 << 14) * scale * scale)
+                for k, spec in enumerate(specs)]
     try:
         items = [s.next_image() for s in sessions]
         sizes, _ = B.glz_encode_batch(sim, items)
@@ -220,6 +222,84 @@ def test_sim_failed_batches_leave_windows_usable(sim, oracle):
     finally:
         for s in sessions:
             s.close()
+
+
+def test_sim_failed_batches_leave_windows_usable(sim, oracle):
+    run_failed_batches(sim, oracle)
+
+
+@pytest.mark.gpu
+def test_gpu_failed_batches_leave_windows_usable(gpu, oracle):
+    run_failed_batches(gpu, oracle, scale=4)
+
+
+def run_two_flights(dev, oracle, n, w, h, nframes, window):
+    """Two batches in flight over disjoint dictionaries: half A's frame k+1 is submitted while
+    half B's frame k still runs.  Every stream equals the oracle's, a third batch and a second
+    batch on a dictionary that is already in flight are refused, and the synchronous drop-in on
+    such a dictionary fails instead of racing."""
+    seqs = [frames.DesktopSequence(max(w, 96), max(h, 96), seed=170 + k) for k in range(n)]
+    ods = [oracle.GlzDict(window, 1) for _ in range(n)]
+    gds = [B.GlzDictionary(dev, window, 1) for _ in range(n)]
+    ges = [B.GlzEncoder(dev, d, 0) for d in gds]
+    cap = dev.L.spice_gpu_glz_out_bound(B.LZ_IMAGE_TYPE_RGB32, w, h)
+    outs = [dev.malloc(cap) for _ in range(n)]
+    imgs = [[np.ascontiguousarray(s.next()[:h, :w]).reshape(h, -1) for _ in range(nframes)] for s in seqs]
+    dev_imgs = [[dev.to_device(im) for im in row] for row in imgs]
+    halves = [list(range(0, n // 2)), list(range(n // 2, n))]
+    try:
+        plans = [B.GlzBatchPlan(dev, [dict(encoder=ges[k], type=B.LZ_IMAGE_TYPE_RGB32, width=w, height=h,
+                                           stride=w * 4, chunks=[dev_imgs[k][0]], chunk_rows=[h],
+                                           out=outs[k], out_capacity=cap) for k in half])
+                 for half in halves]
+        ptrs = lambda a, f: np.array([dev_imgs[k][f] for k in halves[a]], dtype=np.uint64)
+
+        def check(a, f, sizes):
+            for j, k in enumerate(halves[a]):
+                want, _ = ods[k].encode(B.LZ_IMAGE_TYPE_RGB32, w, h, w * 4, [imgs[k][f]])
+                assert_same_stream(want, dev.download(outs[k], int(sizes[j])),
+                                   "two flights: frame %d session %d" % (f, k))
+
+        plans[0].submit(ptrs(0, 0))
+        plans[1].submit(ptrs(1, 0))
+        with pytest.raises(B.SpiceGpuError, match="in flight"):        # a third batch
+            plans[0].submit(ptrs(0, 0))
+        with pytest.raises(B.SpiceGpuError):                           # the synchronous drop-in on a busy dictionary
+            ges[0].encode(B.LZ_IMAGE_TYPE_RGB32, w, h, w * 4, [imgs[0][0]])
+        for f in range(nframes):
+            for a in (0, 1):
+                check(a, f, plans[a].finish())                         # the oldest batch is half a's frame f
+                if f + 1 < nframes:
+                    if a == 0 and f == 0:
+                        # half B is still in flight: a batch that names one of its dictionaries is refused
+                        mixed = B.GlzBatchPlan(dev, [dict(encoder=ges[halves[1][0]], type=B.LZ_IMAGE_TYPE_RGB32,
+                                                          width=w, height=h, stride=w * 4,
+                                                          chunks=[dev_imgs[halves[1][0]][1]], chunk_rows=[h],
+                                                          out=outs[halves[1][0]], out_capacity=cap)])
+                        with pytest.raises(B.SpiceGpuError, match="disjoint"):
+                            mixed.submit()
+                    plans[a].submit(ptrs(a, f + 1))
+        # nothing is in flight any more: the one-call interface works as before
+        with pytest.raises(B.SpiceGpuError, match="without a matching submit"):
+            plans[0].finish()
+    finally:
+        for row in dev_imgs:
+            for p in row:
+                dev.free(p)
+        for k in range(n):
+            dev.free(outs[k])
+            ges[k].close()
+            gds[k].close()
+            ods[k].close()
+
+
+def test_sim_two_flights(sim, oracle):
+    run_two_flights(sim, oracle, 4, 96, 48, 4, window=1 << 15)
+
+
+@pytest.mark.gpu
+def test_gpu_two_flights(gpu, oracle):
+    run_two_flights(gpu, oracle, 12, 640, 400, 5, window=1 << 21)
 
 
 def run_finish_thread_rule(dev, oracle):

@@ -93,7 +93,41 @@ def run_two_encoders(dev, oracle):
         od.close()
 
 
-CASES = [run_reset, run_restore, run_two_encoders]
+def run_restore_large_ids(dev, oracle):
+    """Image ids at and beyond 2^24 and 2^32.  The header carries the id as two 32-bit words and
+    the reference masks the low one with 0xffffff (encode_64, server/glz_encoder.c:83-87), so ids
+    from 2^24 on are written wrongly -- and must be written wrongly in the same way: bytes 21..28
+    of every stream are compared explicitly, the whole stream with the oracle's.  The ids come from
+    glz_enc_dictionary_restore (migration, server/glz_encoder_dictionary.c:178-201), the only way
+    a dictionary starts anywhere but at 0."""
+    imgs, w, h = images(4, 90)
+    for first_id in ((1 << 24) - 2, (1 << 32) - 2):
+        od = oracle.GlzDict(30000, 1, restore_last_id=first_id)
+        data = B.GlzEncDictRestoreData(30000, 1, first_id)
+        gd = B.GlzDictionary(dev, 0, 0, restore=data)
+        ge = B.GlzEncoder(dev, gd, 0)
+        try:
+            for k, px in enumerate(imgs):
+                so, _ = od.encode(T32, w, h, w * 4, [px], usr_tag=k + 1)
+                sg, _ = ge.encode(T32, w, h, w * 4, [px], usr_context=k + 1)
+                image_id = first_id + k
+                want_id = (image_id >> 32).to_bytes(4, "big") + (image_id & 0xffffff).to_bytes(4, "big")
+                assert bytes(sg[21:29]) == want_id, "image id %#x in the header" % image_id
+                assert_same_stream(so, sg, "image id %#x" % image_id)
+            assert gd.get_restore_data().last_image_id == first_id + len(imgs)
+        finally:
+            ge.close()
+            gd.close()
+            od.close()
+
+
+# do_match's reject of image distances above 2^24 - 1 (server/glz_encode_tmpl.c:226-229,
+# glz_encoder.c:195-198) has no test: ids are handed out one by one, so a reference that far
+# back needs more than 2^24 images in one window, a window holds at most 2^25 pixels
+# (glz_encoder_dictionary.c:50), and red_compress_image sends nothing under 54 bytes -- 14 pixels
+# of RGB32 -- through a codec (server/red_worker.c:6423-6426): at most 2.4 million images fit.
+# The kernel carries the test all the same (glz_kernels.hip, scan phase: idist <= 16777215).
+CASES = [run_reset, run_restore, run_two_encoders, run_restore_large_ids]
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda f: f.__name__)

@@ -203,6 +203,27 @@ def test_gpu_mjpeg_api(gpu, oracle):
 
 
 @pytest.mark.gpu
+def test_gpu_mjpeg_api_4k_golden(gpu):
+    """BASELINE configs[2] through the reference's own call shape: a 3840x2160 BGRX frame handed to
+    mjpeg_encoder_start_frame / encode_scanline x 2160 / end_frame (server/red_worker.c:8341-8377),
+    IFAST quality 70 as server/mjpeg_encoder.c:820-822 sets it, against the SHA-256 of real
+    libjpeg's output for that frame (tests/golden/jpeg_golden.json)."""
+    cases = [c for c in jpeg_cases(3840 * 2160)
+             if c["w"] == 3840 and c["h"] == 2160 and c["fmt"] == B.BITMAP_FMT_32BIT and c["q"] == 70
+             and c["dct"] == B.DCT_IFAST]
+    assert cases
+    enc = B.MJpegEncoder(gpu)
+    try:
+        for c in cases[:2]:
+            px = frames.golden_image(c["w"], c["h"], c["kind"], c["seed"]).reshape(c["h"], -1)
+            got = enc.encode_frame(c["fmt"], c["w"], c["h"], px, px.shape[1])
+            assert len(got) == c["len"], c
+            assert hashlib.sha256(np.asarray(got).tobytes()).hexdigest() == c["sha256"], c
+    finally:
+        enc.close()
+
+
+@pytest.mark.gpu
 def test_gpu_still_api(gpu, oracle):
     run_still_api(gpu, oracle)
 

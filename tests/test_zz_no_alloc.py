@@ -2,12 +2,31 @@
 scratch is an array inside the library's code object.  Two calls in a row, the
 second with a smaller frame (the array keeps the first call's contents), each
 compared byte for byte with spice_gpu_jpeg_encode_batch on the same frame; then
-sizes beyond its maximum are refused."""
+sizes beyond its maximum are refused.  That nothing is allocated is checked too: on
+the simulator by counting hipMalloc / hipHostMalloc calls, on the GPU by the free
+device memory before and after."""
+import ctypes
+
 import numpy as np
 import pytest
 
 from spice_amd import binding as B
 from spice_amd import frames
+
+
+def allocation_probe(dev):
+    """a function returning a number that changes when the library allocates"""
+    if hasattr(dev.L, "sim_alloc_calls"):
+        dev.L.sim_alloc_calls.restype = ctypes.c_ulong
+        return lambda: int(dev.L.sim_alloc_calls())
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemGetInfo.argtypes = [ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
+
+    def free_bytes():
+        free, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+        return int(free.value)
+    return free_bytes
 
 
 def both_ways(dev, w, h, kind, seed, quality, dct):
@@ -19,7 +38,10 @@ def both_ways(dev, w, h, kind, seed, quality, dct):
         item = dict(pixels=px, format=B.BITMAP_FMT_32BIT, width=w, height=h, stride=w * 4,
                     quality=quality, dct=dct, out_capacity=cap)
         n_b = B.jpeg_encode_batch(dev, [dict(item, out=out_b)])[0]
+        probe = allocation_probe(dev)
+        before = probe()
         n_a = B.jpeg_encode_noalloc(dev, dict(item, out=out_a))
+        assert probe() == before, "the entry point that allocates nothing allocated"
         a, b = dev.download(out_a, n_a), dev.download(out_b, n_b)
         assert n_a == n_b and (a == b).all(), "%dx%d %s q%d" % (w, h, kind, quality)
         assert a[0] == 0xff and a[1] == 0xd8 and a[-2] == 0xff and a[-1] == 0xd9
