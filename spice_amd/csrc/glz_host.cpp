@@ -14,6 +14,7 @@
  * (glz_encoder_dictionary.c:569-571), which is the only regime in which the
  * reference's output is defined independently of thread timing.
  */
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -31,6 +32,8 @@ using namespace spicegpu;
 
 void glz_launch_parse(const GlzDevJob *jobs, int njobs, unsigned type_mask, const uint32_t *u32_pool,
                       const GlzDevSegUpdate *upd_pool, hipStream_t stream);
+void glz_launch_parse_lone(const GlzDevJob *jobs, int njobs, unsigned type_mask, const uint32_t *u32_pool,
+                           const GlzDevSegUpdate *upd_pool, hipStream_t stream);
 void glz_launch_copy(const GlzCopyDesc *descs, int ndescs, unsigned blocks_per_desc,
                      hipStream_t stream);
 
@@ -744,6 +747,27 @@ struct LaunchStreams {
     hipEvent_t fork, join;
 };
 
+/* Launches of at most this many images use the kernel for an under-filled GPU: the number of
+ * CUs of the device, or what SPICE_GPU_GLZ_LONE_MAX says (0: never; for measurements). */
+int lone_max_jobs()
+{
+    static int cached = -1;
+    if (cached < 0) {
+        int v = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, current_device() < 0 ? 0 : current_device()) == hipSuccess &&
+            prop.multiProcessorCount > 0) {
+            v = prop.multiProcessorCount;
+        }
+        const char *e = getenv("SPICE_GPU_GLZ_LONE_MAX");
+        if (e && *e) {
+            v = atoi(e);
+        }
+        cached = v;
+    }
+    return cached;
+}
+
 /* Lays jobs, pools and copy descriptors out in the staging buffer, uploads
  * them and enqueues copy + parse.  copy_on_device: the chunk sources are
  * device pointers (batch path); otherwise the caller has already enqueued
@@ -805,17 +829,19 @@ bool launch(Prepared *const *jobs, size_t n, Staging &st, size_t *results_off, b
     if (!check(hipMemcpyAsync(st.dev, st.host, off_res, hipMemcpyHostToDevice, s), "upload jobs")) {
         return false;
     }
-    /* When every image of the batch is parsed from its caller's buffer, the copies
-     * into the arenas run on the side stream beside the parse; stream() waits
-     * for them at the end, so whoever synchronises it has both. */
-    bool beside = copy_on_device && n_copy != 0 && ls.side != nullptr;
+    /* When every image of the batch is parsed from its caller's buffer, the copies into the
+     * arenas only serve later images: they follow the parse, on the side stream beside it
+     * (stream() waits for them at the end, so whoever synchronises it has both) or, without
+     * one, behind it on the same stream, where they run beside the other flights' parses. */
+    bool own_all = copy_on_device && n_copy != 0;
     for (size_t j = 0; j < n; j++) {
-        beside = beside && jobs[j]->dev.own_src != nullptr;
+        own_all = own_all && jobs[j]->dev.own_src != nullptr;
     }
+    const bool beside = own_all && ls.side != nullptr;
     uint64_t per_block = 256ull * 16 * 8; /* 8 vectors per lane */
     unsigned blocks = (unsigned)((max_copy + per_block - 1) / per_block);
     blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
-    if (copy_on_device && n_copy && !beside) {
+    if (copy_on_device && n_copy && !own_all) {
         glz_launch_copy((const GlzCopyDesc *)(st.dev + off_copy), (int)n_copy, blocks, s);
     }
     if (beside && !check(hipEventRecord(ls.fork, s), "event")) {
@@ -825,9 +851,18 @@ bool launch(Prepared *const *jobs, size_t n, Staging &st, size_t *results_off, b
     for (size_t j = 0; j < n; j++) {
         type_mask |= 1u << jobs[j]->dev.type;
     }
-    glz_launch_parse((const GlzDevJob *)(st.dev + off_jobs), (int)n, type_mask,
-                     (const uint32_t *)(st.dev + off_u32),
-                     (const GlzDevSegUpdate *)(st.dev + off_upd), s);
+    /* Fewer images than the GPU has CUs: every image gets a CU to itself and the kernel that
+     * runs scan, walk and emit side by side (glz_lone.hip); a full GPU is served best by
+     * the kernel that fits eight images on a CU.  Same streams either way. */
+    if ((int)n <= lone_max_jobs()) {
+        glz_launch_parse_lone((const GlzDevJob *)(st.dev + off_jobs), (int)n, type_mask,
+                              (const uint32_t *)(st.dev + off_u32),
+                              (const GlzDevSegUpdate *)(st.dev + off_upd), s);
+    } else {
+        glz_launch_parse((const GlzDevJob *)(st.dev + off_jobs), (int)n, type_mask,
+                         (const uint32_t *)(st.dev + off_u32),
+                         (const GlzDevSegUpdate *)(st.dev + off_upd), s);
+    }
     if (beside) {
         /* after the parse, so that the parse's workgroups take their places first
          * and the copy fills what is left of the CUs */
@@ -839,6 +874,8 @@ bool launch(Prepared *const *jobs, size_t n, Staging &st, size_t *results_off, b
         if (!check(hipEventRecord(ls.join, cs), "event")) {
             return false;
         }
+    } else if (own_all) {
+        glz_launch_copy((const GlzCopyDesc *)(st.dev + off_copy), (int)n_copy, blocks, s);
     }
     if (!check(hipGetLastError(), "glz launch")) {
         return false;

@@ -1,0 +1,301 @@
+/*
+ * One segment (glz_encode_tmpl.c:268-491) for the kernel of glz_lone.hip: a GPU
+ * that holds fewer sessions than it has CUs gives every session a CU of its own,
+ * and what then counts is how soon ONE image is through.  The phases of
+ * glz_parse_phases.h run side by side on three windows instead of one after the
+ * other on one; nine wavefronts:
+ *
+ *   wavefront 0       walks window w (glz_window_resolve), and does nothing else
+ *   wavefronts 1-4    meanwhile scan window w+1 -- on the guess that the walk leaves
+ *                     window w into the 256 positions behind it -- without knowing
+ *                     which positions of window w will have been stored to the table
+ *   wavefronts 5-8    meanwhile write window w-1's tokens (glz_window_emit)
+ *
+ * and when the walk is through: wavefronts 5-8 make window w's table stores, and
+ * wavefronts 1-4 put right what the scan of window w+1 could not know -- a position
+ * whose table slot window w stored to gets that store as its table candidate
+ * (glz_window_fixup; both windows' pixels are in LDS) -- or, when the walk went
+ * somewhere else, throw the scan away and scan the right window in the next step
+ * while wavefront 0 waits.  The stops, the table contents every stop sees and the
+ * bytes written are those of the one-window kernel; the windows merely start at
+ * other positions, which the format does not know of.
+ *
+ * Included by glz_parse_phases.h when GLZ_LONE is defined.
+ */
+
+#define GLZ_LONE_THREADS 576
+enum { GLZ_ROLE_WALK = 0, GLZ_ROLE_SCAN = 1, GLZ_ROLE_EMIT = 2 };
+
+#ifdef GLZ_LONE_STAMPS
+__device__ unsigned long long glz_lone_stamp_acc[16];
+extern "C" void spice_gpu_debug_lone_stamps(unsigned long long *out, int reset)
+{
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(glz_lone_stamp_acc), sizeof(unsigned long long) * 16);
+    if (reset) {
+        unsigned long long z[16] = {0};
+        hipMemcpyToSymbol(HIP_SYMBOL(glz_lone_stamp_acc), z, sizeof(z));
+    }
+}
+#define LONE_CLOCK() clock64()
+#else
+#define LONE_CLOCK() 0ll
+#endif
+
+/* the tile of the window that starts at ip: positions ip-1 .. ip+WIN+K+2, and ip-2 apart */
+template <int MODE>
+__device__ __forceinline__ void glz_load_tile(GlzWin &win, const GLZ_GLOBAL uint8_t *base, int ip, int npix, int t)
+{
+    for (int k = t; k < GLZ_TILE; k += GLZ_WIN) {
+        const int pos = ip - 1 + k;
+        win.tile[k] = (pos >= 0 && pos < npix) ? glz_load_px<MODE>(base, pos) : 0u;
+    }
+    if (t == GLZ_WIN - 1) {
+        win.tile_m2 = ip >= 2 ? glz_load_px<MODE>(base, ip - 2) : 0u;
+    }
+}
+
+/* Window `win` (first position ip) was scanned before the walk of the window in front of it,
+ * `prev` (first position ip_prev, same segment), had made its table stores.  A position
+ * whose slot one of those stores went to sees the newest of them where the scan saw the
+ * table: validation and do_match's rules as in glz_window_scan (2) and (4), for a reference
+ * in the same segment whose pixels are in prev's tile.  One position per lane. */
+template <int MODE>
+__device__ __forceinline__ void glz_window_fixup(GlzWin &win, const GlzWin &prev, uint32_t seg_idx, int ip,
+                                                 int ip_prev, int npix, int tid)
+{
+    typedef GlzTraits<MODE> T;
+    const int p = tid, q = ip + p;
+    uint32_t A = win.infoA[p];
+    if (!(A & GLZ_A_ACT) || (A & GLZ_A_RLE)) {
+        return; /* no table look-up here */
+    }
+    const uint32_t h = win.hash[p];
+    const uint32_t key = h & (GLZ_KEYS - 1);
+    const uint32_t *ins32 = (const uint32_t *)prev.ins;
+    int j = -1;
+    for (int v = 7; v >= 0 && j < 0; v--) {
+        uint32_t bits = prev.bitmap[GLZ_BM(key, (uint32_t)v)] & ins32[v];
+        while (bits && j < 0) {
+            const int b = 31 - __clz((int)bits);
+            bits &= ~(1u << b);
+            if (prev.hash[v * 32 + b] == h) {
+                j = v * 32 + b;
+            }
+        }
+    }
+    if (j < 0) {
+        return; /* the slot was not stored to: what the scan read stands */
+    }
+    const int ref = ip_prev + j;
+    const int maxn = (npix - 2) - q; /* the reference's own limit lies further on: ref < q */
+    const uint32_t pdist = (uint32_t)(q - ref);
+    const bool capped = maxn > GLZ_K;
+    const int maxk = capped ? GLZ_K : maxn;
+    int len = 0;
+    bool run = true;
+#pragma unroll
+    for (int k = 0; k < GLZ_K; k++) {
+        run = run && k < maxk && ((win.tile[p + 1 + k] ^ prev.tile[j + 1 + k]) & T::MASK) == 0;
+        len += run ? 1 : 0;
+    }
+    if (len >= T::MIN_REF && len <= T::MAX_REF) {
+        /* glz_encode_tmpl.c:243-261 */
+        const int need = glz_ref_bytes(0, pdist) / T::ENC_DIV + 1;
+        if (len < need) {
+            len = 0;
+        }
+    }
+    A &= ~((31u << GLZ_A_GLEN_SHIFT) | GLZ_A_GMAX);
+    if (len >= T::MIN_REF) {
+        A |= ((uint32_t)len << GLZ_A_GLEN_SHIFT) | (capped && len == GLZ_K ? GLZ_A_GMAX : 0u);
+        win.g_ref[p] = (uint32_t)ref;
+        win.g_seg[p] = seg_idx;
+        win.g_idist[p] = 0;
+        win.g_pdist[p] = pdist;
+    }
+    win.infoA[p] = A;
+}
+
+/* All GLZ_LONE_THREADS lanes call this.  from: first position to parse (2 in an image's
+ * first segment, whose two leading pixels are already out as literals). */
+template <int MODE>
+__device__ __forceinline__ void glz_parse_seg(const GlzDevJob &job, uint32_t seg_idx, int from, int tid)
+{
+    GlzShared &sh = glz_sh;
+    const int lane = tid & 63;
+    const int wave = (int)glz_uniform((uint32_t)(tid >> 6));
+    const int role = wave == 0 ? GLZ_ROLE_WALK : (wave <= 4 ? GLZ_ROLE_SCAN : GLZ_ROLE_EMIT);
+    const int gt = role == GLZ_ROLE_SCAN ? tid - GLZ_WAVE : (role == GLZ_ROLE_EMIT ? tid - 5 * GLZ_WAVE : tid);
+    const GlzDevSeg cs = glz_seg_uniform(glz_seg(job, sh, seg_idx));
+    const GLZ_GLOBAL uint8_t *base = glz_seg_base(job, seg_idx, cs);
+    const int npix = (int)cs.nunits;
+    const int ip_limit = npix - 6;
+
+    if (tid == 0) {
+        sh.arrive[0] = sh.arrive[1] = 0;
+    }
+    __syncthreads();
+    uint32_t tgt = 0;      /* arrivals this lane's group barrier waits for next */
+
+    int ip = from;         /* where the next window that must be scanned afresh starts */
+    uint32_t pend = 0;     /* table stores the last match left for positions ip-2, ip-1 of such a window */
+    int cur = 0;           /* slot of the window the walk takes next */
+    bool ready = false;    /* ... it is scanned */
+    int cur_ip = 0, ent_i = 0, ent_t0 = -1, ent_t1 = -1;
+    int prv = -1, prv_ip = 0; /* slot and start of the window whose tokens are not out yet */
+#ifdef GLZ_LONE_STAMPS
+    long long a_p1 = 0, a_p2 = 0, a_role = 0, n_steps = 0, n_hits = 0, n_bubbles = 0, n_spec = 0;
+#endif
+
+    while (ready || prv >= 0 || ip < ip_limit) {
+        const int nxt = cur == GLZ_SLOTS - 1 ? 0 : cur + 1;
+        const int nxt_ip = cur_ip + GLZ_WIN;
+        const bool spec = ready && nxt_ip < ip_limit;
+#ifdef GLZ_LONE_STAMPS
+        const long long c0 = LONE_CLOCK();
+#endif
+        /* ---- the three phases, side by side */
+        if (role == GLZ_ROLE_WALK) {
+            if (ready) {
+#ifndef SPICE_WAVE_SIM
+                __builtin_amdgcn_s_setprio(3);
+#endif
+                glz_window_resolve<MODE>(sh.win[cur], job, seg_idx, base, cur_ip, npix, lane, ent_i, ent_t0, ent_t1);
+#ifndef SPICE_WAVE_SIM
+                __builtin_amdgcn_s_setprio(0);
+#endif
+            }
+        } else if (role == GLZ_ROLE_SCAN) {
+            if (ready ? spec : ip < ip_limit) {
+                GlzWin &w = sh.win[ready ? nxt : cur];
+                const int s_ip = ready ? nxt_ip : ip;
+                glz_load_tile<MODE>(w, base, s_ip, npix, gt);
+                glz_group_barrier(&sh.arrive[0], tgt, lane);
+                /* a window scanned afresh: the table stores the last match left behind, now
+                 * that the pixels are here (position ip-2 first, then ip-1, as the reference
+                 * orders them).  A window scanned ahead of the walk has them inside it. */
+                const uint32_t pd = ready ? 0u : pend;
+                uint32_t th0 = GLZ_NO_HASH, th1 = GLZ_NO_HASH;
+                if (pd) {
+                    typedef GlzTraits<MODE> T;
+                    const uint32_t a = w.tile_m2 & T::MASK, b = w.tile[0] & T::MASK;
+                    const uint32_t c = w.tile[1] & T::MASK, d = w.tile[2] & T::MASK;
+                    th0 = glz_hash3<MODE>(a, b, c);
+                    th1 = glz_hash3<MODE>(b, c, d);
+                    if (gt == 0) {
+                        if (pd & 1u) {
+                            glz_htab_store(job, th0, seg_idx, (uint32_t)(s_ip - 2));
+                        }
+                        if (pd & 2u) {
+                            glz_htab_store(job, th1, seg_idx, (uint32_t)(s_ip - 1));
+                        }
+                    }
+                }
+                uint32_t my_h;
+                bool my_hv;
+                glz_window_scan<MODE>(w, job, cs, seg_idx, base, s_ip, npix, gt, pd, th0, th1, my_h, my_hv, tgt);
+            }
+        } else if (prv >= 0) {
+            const uint32_t my_h = sh.win[prv].hash[gt];
+            glz_window_emit<MODE>(sh.win[prv], job, seg_idx, prv_ip, gt, my_h, prv_ip + gt + 2 < npix, tgt, false);
+        }
+#ifdef GLZ_LONE_STAMPS
+        const long long c1 = LONE_CLOCK();
+#endif
+        __syncthreads();
+#ifdef GLZ_LONE_STAMPS
+        const long long c2 = LONE_CLOCK();
+#endif
+        /* ---- what depends on where the walk ended */
+        if (ready) {
+            const GlzWin &cw = sh.win[cur];
+            const int next_ip = (int)glz_uniform((uint32_t)cw.next_ip);
+            const int r0 = (int)glz_uniform((uint32_t)cw.tail0), r1 = (int)glz_uniform((uint32_t)cw.tail1);
+            const uint32_t cpend = glz_uniform(cw.pend);
+            const bool hit = spec && next_ip >= nxt_ip && next_ip < nxt_ip + GLZ_WIN && next_ip < ip_limit;
+            if (role == GLZ_ROLE_EMIT) {
+                const uint32_t my_h = cw.hash[gt];
+                glz_window_emit<MODE>(sh.win[cur], job, seg_idx, cur_ip, gt, my_h, cur_ip + gt + 2 < npix, tgt, true);
+            } else if (role == GLZ_ROLE_SCAN && spec) {
+                if (hit) {
+                    glz_window_fixup<MODE>(sh.win[nxt], cw, seg_idx, nxt_ip, cur_ip, npix, gt);
+                } else if (nxt_ip + gt + 2 < npix) {
+                    /* the guess was wrong: the slot's bitmap is clean again for its next window */
+                    sh.win[nxt].bitmap[GLZ_BM(sh.win[nxt].hash[gt] & (GLZ_KEYS - 1), (uint32_t)gt >> 5)] = 0;
+                }
+            }
+            __syncthreads();
+            prv = cur;
+            prv_ip = cur_ip;
+            cur = nxt;
+            ip = next_ip;
+            if (hit) {
+                cur_ip = nxt_ip;
+                ent_i = next_ip - nxt_ip;
+                ent_t0 = r0 >= GLZ_WIN ? r0 - GLZ_WIN : -1;
+                ent_t1 = r1 >= GLZ_WIN ? r1 - GLZ_WIN : -1;
+                pend = 0;
+            } else {
+                ready = false;
+                pend = cpend;
+            }
+#ifdef GLZ_LONE_STAMPS
+            n_hits += hit ? 1 : 0;
+            n_spec += spec ? 1 : 0;
+#endif
+        } else {
+            /* the scan (if any) has filled win[cur]; the tokens of prv are out */
+            if (ip < ip_limit) {
+                ready = true;
+                cur_ip = ip;
+                ent_i = 0;
+                ent_t0 = ent_t1 = -1;
+            }
+            prv = -1;
+#ifdef GLZ_LONE_STAMPS
+            n_bubbles++;
+#endif
+        }
+#ifdef GLZ_LONE_STAMPS
+        const long long c3 = LONE_CLOCK();
+        a_role += c1 - c0;
+        a_p1 += c2 - c0;
+        a_p2 += c3 - c2;
+        n_steps++;
+#endif
+    }
+#ifdef GLZ_LONE_STAMPS
+    if (lane == 0 && (wave == 0 || wave == 1 || wave == 5)) {
+        const int r = wave == 0 ? 0 : (wave == 1 ? 1 : 2);
+        atomicAdd(&glz_lone_stamp_acc[r], (unsigned long long)a_role); /* own work in the side-by-side part */
+        if (wave == 0) {
+            atomicAdd(&glz_lone_stamp_acc[3], (unsigned long long)a_p1);
+            atomicAdd(&glz_lone_stamp_acc[4], (unsigned long long)a_p2);
+            atomicAdd(&glz_lone_stamp_acc[5], (unsigned long long)n_steps);
+            atomicAdd(&glz_lone_stamp_acc[6], (unsigned long long)n_hits);
+            atomicAdd(&glz_lone_stamp_acc[7], (unsigned long long)n_bubbles);
+            atomicAdd(&glz_lone_stamp_acc[8], (unsigned long long)n_spec);
+        }
+    }
+#endif
+
+    /* ---- leftovers as literals, then the run closes; glz_encode_tmpl.c:466-487 */
+    if (role == GLZ_ROLE_WALK) {
+        /* stores the last window's last match left behind: no tile follows */
+        if (pend & 1u) {
+            const uint32_t th0 = glz_hash_at<MODE>(base, ip - 2);
+            if (lane == 0) {
+                glz_htab_store(job, th0, seg_idx, (uint32_t)(ip - 2));
+            }
+        }
+        if (pend & 2u) {
+            const uint32_t th1 = glz_hash_at<MODE>(base, ip - 1);
+            if (lane == 0) {
+                glz_htab_store(job, th1, seg_idx, (uint32_t)(ip - 1));
+            }
+        }
+        glz_run_from_arena<MODE>(job, base, ip, npix - ip, true, lane);
+    }
+    __syncthreads();
+}

@@ -140,6 +140,9 @@ void sim_barrier(int scope_wave);
 uint64_t sim_exchange64(uint64_t v, int src_lane_or_neg, int mode, int arg);
 /* mode 0: ballot (v = predicate); 1: shfl abs lane=arg; 2: up by arg; 3: down by arg; 4: xor arg */
 
+/* barrier of nthreads work-items of the workgroup that meet at `key` (wavefronts sharing a phase) */
+void sim_group_barrier(void *key, int nthreads);
+
 static inline void __syncthreads() { sim_barrier(0); }
 static inline uint64_t __ballot(int pred) { return sim_exchange64(pred ? 1 : 0, -1, 0, 0); }
 static inline int __any(int pred) { return __ballot(pred) != 0; }

@@ -48,6 +48,7 @@ int n_fibers, cur_fiber;
 void *sched_sp;
 const std::function<void()> *cur_body;
 uint64_t progress; /* bumped whenever any fiber gets past a rendezvous or ends */
+void *wait_site[4096]; /* where each fiber last entered a collective */
 
 /* per wave rendezvous */
 uint64_t slot[kMaxThreads];
@@ -129,12 +130,37 @@ void rendezvous_block()
 
 } // namespace
 
-static void *wait_site[4096]; /* where each fiber last entered a collective */
 
 void sim_barrier(int)
 {
     wait_site[cur_fiber] = __builtin_return_address(0);
     rendezvous_block();
+}
+
+/* Barrier of a subset of the workgroup's work-items (the wavefronts that share one phase of a
+ * kernel in which phases run side by side): nthreads arrivals at `key` release them all. */
+namespace {
+struct GroupBarrier {
+    int arrived = 0;
+    uint64_t gen = 0;
+};
+std::map<void *, GroupBarrier> group_barriers;
+} // namespace
+
+void sim_group_barrier(void *key, int nthreads)
+{
+    wait_site[cur_fiber] = __builtin_return_address(0);
+    GroupBarrier &b = group_barriers[key];
+    if (++b.arrived == nthreads) {
+        b.arrived = 0;
+        b.gen++;
+        progress++;
+    } else {
+        uint64_t g = b.gen;
+        while (b.gen == g) {
+            yield_to_sched();
+        }
+    }
 }
 
 uint64_t sim_exchange64(uint64_t v, int, int mode, int arg)
