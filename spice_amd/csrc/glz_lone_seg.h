@@ -27,13 +27,13 @@
 enum { GLZ_ROLE_WALK = 0, GLZ_ROLE_SCAN = 1, GLZ_ROLE_EMIT = 2 };
 
 #ifdef GLZ_LONE_STAMPS
-__device__ unsigned long long glz_lone_stamp_acc[16];
+__device__ unsigned long long glz_lone_stamp_acc[32];
 extern "C" void spice_gpu_debug_lone_stamps(unsigned long long *out, int reset)
 {
     hipDeviceSynchronize();
-    hipMemcpyFromSymbol(out, HIP_SYMBOL(glz_lone_stamp_acc), sizeof(unsigned long long) * 16);
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(glz_lone_stamp_acc), sizeof(unsigned long long) * 32);
     if (reset) {
-        unsigned long long z[16] = {0};
+        unsigned long long z[32] = {0};
         hipMemcpyToSymbol(HIP_SYMBOL(glz_lone_stamp_acc), z, sizeof(z));
     }
 }
@@ -117,6 +117,77 @@ __device__ __forceinline__ void glz_window_fixup(GlzWin &win, const GlzWin &prev
     win.infoA[p] = A;
 }
 
+/* The scanning wavefronts, once a window's scan is through: the long matches the walk will
+ * want, measured while it is still busy with the window in front.  A table candidate that
+ * agreed over all GLZ_K pixels of the scan's compare costs the walk a compare in global memory,
+ * round trip after round trip with nothing else to do (glz_resolve_general); here each of
+ * the four wavefronts takes one head (see GlzWin) and has the length ready.  The match that
+ * takes the walk out of a window is the last one it makes there, so the heads taken are
+ * the window's last four.  May run while the window is being walked (a window that was
+ * scanned with the walk waiting for it): a record counts once its bit in heads_ready is set. */
+template <int MODE>
+__device__ __forceinline__ void glz_window_heads(GlzWin &w, const GlzDevJob &job, const GLZ_GLOBAL uint8_t *base,
+                                                 int ip, int npix, int gt, uint32_t &tgt)
+{
+    GlzShared &sh = glz_sh;
+    const int lane = gt & 63, p = gt;
+    const int wg = (int)glz_uniform((uint32_t)(gt >> 6));
+    glz_group_barrier(&sh.arrive[0], tgt, lane); /* every position's scan results are in LDS */
+    const uint32_t A = w.infoA[p];
+    const bool gmax = (A & GLZ_A_GMAX) != 0;
+    const uint32_t seg = w.g_seg[p];
+    const int delta = (int)w.g_ref[p] - (ip + p);
+    bool goes_on = false;
+    if (p > 0 && gmax) {
+        goes_on = (w.infoA[p - 1] & GLZ_A_GMAX) && w.g_seg[p - 1] == seg &&
+                  (int)w.g_ref[p - 1] - (ip + p - 1) == delta;
+    }
+    const uint64_t hm = __ballot(gmax && !goes_on);
+    if (lane == 0) {
+        w.headmask[wg] = hm;
+    }
+    glz_group_barrier(&sh.arrive[0], tgt, lane);
+    /* this wavefront's head: the wg-th from the window's end */
+    int pos = -1, skip = wg;
+#pragma unroll
+    for (int v = 3; v >= 0; v--) {
+        uint64_t m = glz_uniform64(w.headmask[v]);
+        const int c = __popcll(m);
+        if (pos < 0 && skip >= 0 && skip < c) {
+            for (int k = 0; k < skip; k++) {
+                m &= ~(1ull << (63 - __clzll((long long)m)));
+            }
+            pos = v * 64 + 63 - __clzll((long long)m);
+        }
+        skip -= c;
+    }
+    int end = 0;
+    bool gave_up = false;
+    uint32_t hseg = 0;
+    int hdelta = 0;
+    if (pos >= 0) {
+        hseg = glz_uniform(w.g_seg[pos]);
+        const int ref = (int)glz_uniform(w.g_ref[pos]);
+        const GlzDevSeg rs = glz_seg(job, sh, hseg);
+        const GLZ_GLOBAL uint8_t *rbase = glz_seg_base(job, hseg, rs);
+        const int q = ip + pos;
+        int maxn = (npix - 2) - q;
+        const int rmax = (int)rs.nunits - ref;
+        maxn = rmax < maxn ? rmax : maxn;
+        hdelta = ref - q;
+        end = q + glz_match_len<MODE, true>(base, q, rbase, ref, GLZ_K, maxn, lane, GLZ_HEAD_ROUNDS, &gave_up);
+    }
+    if (lane == 0) {
+        w.head_pos[wg] = pos;
+        w.head_seg[wg] = hseg;
+        w.head_delta[wg] = hdelta;
+        w.head_end[wg] = end;
+        w.head_done[wg] = gave_up ? 0 : 1;
+        __threadfence_block();
+        atomicOr(&w.heads_ready, 1u << wg);
+    }
+}
+
 /* All GLZ_LONE_THREADS lanes call this.  from: first position to parse (2 in an image's
  * first segment, whose two leading pixels are already out as literals). */
 template <int MODE>
@@ -134,6 +205,12 @@ __device__ __forceinline__ void glz_parse_seg(const GlzDevJob &job, uint32_t seg
 
     if (tid == 0) {
         sh.arrive[0] = sh.arrive[1] = 0;
+#ifdef GLZ_LONE_STAMPS
+        sh.st_fast = 0;
+        for (int k = 0; k < 5; k++) {
+            sh.st_gen[k] = sh.st_ngen[k] = 0;
+        }
+#endif
     }
     __syncthreads();
     uint32_t tgt = 0;      /* arrivals this lane's group barrier waits for next */
@@ -144,6 +221,7 @@ __device__ __forceinline__ void glz_parse_seg(const GlzDevJob &job, uint32_t seg
     bool ready = false;    /* ... it is scanned */
     int cur_ip = 0, ent_i = 0, ent_t0 = -1, ent_t1 = -1;
     int prv = -1, prv_ip = 0; /* slot and start of the window whose tokens are not out yet */
+    bool heads_due = false;   /* win[cur]'s long matches have not been measured yet */
 #ifdef GLZ_LONE_STAMPS
     long long a_p1 = 0, a_p2 = 0, a_role = 0, n_steps = 0, n_hits = 0, n_bubbles = 0, n_spec = 0;
 #endif
@@ -167,10 +245,17 @@ __device__ __forceinline__ void glz_parse_seg(const GlzDevJob &job, uint32_t seg
 #endif
             }
         } else if (role == GLZ_ROLE_SCAN) {
+            if (ready && heads_due) {
+                /* the window under the walk was scanned with the walk waiting for it */
+                glz_window_heads<MODE>(sh.win[cur], job, base, cur_ip, npix, gt, tgt);
+            }
             if (ready ? spec : ip < ip_limit) {
                 GlzWin &w = sh.win[ready ? nxt : cur];
                 const int s_ip = ready ? nxt_ip : ip;
                 glz_load_tile<MODE>(w, base, s_ip, npix, gt);
+                if (gt == 0) {
+                    w.heads_ready = 0;
+                }
                 glz_group_barrier(&sh.arrive[0], tgt, lane);
                 /* a window scanned afresh: the table stores the last match left behind, now
                  * that the pixels are here (position ip-2 first, then ip-1, as the reference
@@ -195,6 +280,9 @@ __device__ __forceinline__ void glz_parse_seg(const GlzDevJob &job, uint32_t seg
                 uint32_t my_h;
                 bool my_hv;
                 glz_window_scan<MODE>(w, job, cs, seg_idx, base, s_ip, npix, gt, pd, th0, th1, my_h, my_hv, tgt);
+                if (ready) {
+                    glz_window_heads<MODE>(w, job, base, s_ip, npix, gt, tgt);
+                }
             }
         } else if (prv >= 0) {
             const uint32_t my_h = sh.win[prv].hash[gt];
@@ -230,6 +318,7 @@ __device__ __forceinline__ void glz_parse_seg(const GlzDevJob &job, uint32_t seg
             prv_ip = cur_ip;
             cur = nxt;
             ip = next_ip;
+            heads_due = false;
             if (hit) {
                 cur_ip = nxt_ip;
                 ent_i = next_ip - nxt_ip;
@@ -248,6 +337,7 @@ __device__ __forceinline__ void glz_parse_seg(const GlzDevJob &job, uint32_t seg
             /* the scan (if any) has filled win[cur]; the tokens of prv are out */
             if (ip < ip_limit) {
                 ready = true;
+                heads_due = true;
                 cur_ip = ip;
                 ent_i = 0;
                 ent_t0 = ent_t1 = -1;
@@ -276,6 +366,11 @@ __device__ __forceinline__ void glz_parse_seg(const GlzDevJob &job, uint32_t seg
             atomicAdd(&glz_lone_stamp_acc[6], (unsigned long long)n_hits);
             atomicAdd(&glz_lone_stamp_acc[7], (unsigned long long)n_bubbles);
             atomicAdd(&glz_lone_stamp_acc[8], (unsigned long long)n_spec);
+            atomicAdd(&glz_lone_stamp_acc[9], (unsigned long long)sh.st_fast);
+            for (int k = 0; k < 5; k++) {
+                atomicAdd(&glz_lone_stamp_acc[10 + k], (unsigned long long)sh.st_gen[k]);
+                atomicAdd(&glz_lone_stamp_acc[15 + k], (unsigned long long)sh.st_ngen[k]);
+            }
         }
     }
 #endif

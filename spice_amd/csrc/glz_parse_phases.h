@@ -279,13 +279,17 @@ __device__ __forceinline__ int glz_agree4(const glz_u32x4 a, const glz_u32x4 b, 
  * plus start.  One wavefront; every load of an iteration is in flight before
  * the first compare.  Lanes past the end re-read the last whole group; no
  * byte beyond position maxn - 1 of either side is touched. */
-template <int MODE>
+template <int MODE, bool BUDGETED = false>
 __device__ __forceinline__ int glz_match_len(const GLZ_GLOBAL uint8_t *sbase, int sidx,
                                              const GLZ_GLOBAL uint8_t *rbase, int ridx, int start,
-                                             int maxn, int lane)
+                                             int maxn, int lane, int max_rounds = 0, bool *gave_up = nullptr)
 {
+    /* BUDGETED: after max_rounds round trips without a difference the compare gives up;
+     * *gave_up says so, and the positions before the returned one are known to agree */
     typedef GlzTraits<MODE> T;
     int n = start;
+    int rounds = 0;
+    bool out_of_rounds = false;
     if (MODE == GLZ_MODE_RGB32 || MODE == GLZ_MODE_ALPHA) {
         const uint32_t mask = glz_raw_mask<MODE>();
         const int lim = maxn - 3; /* a group of four never reaches past maxn - 1 */
@@ -323,6 +327,10 @@ __device__ __forceinline__ int glz_match_len(const GLZ_GLOBAL uint8_t *sbase, in
                 }
             }
             if (done) {
+                break;
+            }
+            if (BUDGETED && ++rounds >= max_rounds && n < lim) {
+                out_of_rounds = true;
                 break;
             }
         }
@@ -367,7 +375,14 @@ __device__ __forceinline__ int glz_match_len(const GLZ_GLOBAL uint8_t *sbase, in
             if (done) {
                 break;
             }
+            if (BUDGETED && ++rounds >= max_rounds && n < maxn) {
+                out_of_rounds = true;
+                break;
+            }
         }
+    }
+    if (BUDGETED) {
+        *gave_up = out_of_rounds;
     }
     return n < maxn ? n : maxn;
 }
@@ -505,8 +520,16 @@ __device__ __forceinline__ void glz_group_barrier(uint32_t *ctr, uint32_t &targe
 }
 #endif
 
+#ifdef GLZ_LONE_STAMPS
+#define LONE_STAMP() clock64()
+#define LONE_CLASS(c) do { if (lane == 0) glz_sh.st_class = (c); } while (0)
+#else
+#define LONE_CLASS(c) do { } while (0)
+#endif
 /* The kernel for a GPU with few sessions keeps three windows in LDS: one being scanned,
  * one being walked, one being written out (glz_lone.hip). */
+#define GLZ_HEADS 4
+#define GLZ_HEAD_ROUNDS 8              /* round trips a compare ahead of the walk may take */
 struct GlzWin {                        /* what one window needs from its scan to its emit */
     uint32_t tile[GLZ_TILE];
     uint32_t hash[GLZ_WIN];
@@ -526,6 +549,18 @@ struct GlzWin {                        /* what one window needs from its scan to
     uint32_t pend;
     int next_ip;
     int tail0, tail1;                  /* where the walk's last match stored behind itself, window positions (-1: nowhere) */
+    int start_ip;                      /* the window's first position, as the scanning wavefronts chose it */
+    int jump;                          /* ... 1: where a long match of the window in front ends; 0: right behind that window */
+    /* Long matches against the table's candidates, measured ahead of the walk (glz_window_heads):
+     * a head is the first of consecutive positions whose candidates lie at one distance in one
+     * segment -- one match seen from each of them -- and ends where that match ends. */
+    uint64_t headmask[4];
+    int head_pos[GLZ_HEADS];           /* window position, -1: none */
+    uint32_t head_seg[GLZ_HEADS];      /* the candidates' segment */
+    int head_delta[GLZ_HEADS];         /* candidate's pixel index minus the position's */
+    int head_end[GLZ_HEADS];           /* first position of this segment that differs (or the limit) */
+    int head_done[GLZ_HEADS];          /* 0: the compare gave up at head_end, the match may go on */
+    uint32_t heads_ready;              /* bit h: head h's record is complete (it may be written while the window is walked) */
 };
 #define GLZ_SLOTS 3
 struct GlzShared {
@@ -534,8 +569,9 @@ struct GlzShared {
     uint32_t wave_sum[4];
     uint32_t op, copy, last_copy;      /* output cursor, see below */
     uint32_t arrive[2];                /* arrivals at the barriers of the scanning and the emitting wavefronts */
-#ifdef GLZ_STAMPS
-    long long st_walk, st_scan_t, st_emit_t, st_pub, st_steps, st_hits, st_bubbles;
+#ifdef GLZ_LONE_STAMPS
+    long long st_fast, st_gen[5], st_ngen[5]; /* the walk: fast loop; general path by kind */
+    int st_class;
 #endif
 };
 static_assert(sizeof(GlzShared) <= 64 * 1024, "one workgroup's static LDS");
@@ -553,7 +589,10 @@ static_assert(sizeof(GlzShared) <= 64 * 1024, "one workgroup's static LDS");
 #define GLZ_GROUP_ARG , uint32_t &grp_target
 /* stores: this call makes the window's table stores and nothing else; otherwise it writes the
  * window's tokens and makes no table store */
-#define GLZ_EMIT_ARG , uint32_t &grp_target, bool stores
+#define GLZ_EMIT_ARG , uint32_t &grp_target, bool stores, uint32_t later_h0, uint32_t later_h1
+/* later_h0 / later_h1: slots that will be stored to right after this window's stores (the
+ * positions behind the match that led out of it), GLZ_NO_HASH for none */
+#define GLZ_DOMINATED_AT_ONCE (my_h == later_h0 || my_h == later_h1)
 #else
 struct GlzShared {
     uint32_t tile[GLZ_TILE];           /* raw pixels of positions ip-1 .. */
@@ -599,6 +638,8 @@ static_assert(sizeof(GlzShared) <= 20 * 1024, "eight workgroups per CU share 160
 #define GLZ_PHASE_BARRIER(which) __syncthreads()
 #define GLZ_GROUP_ARG
 #define GLZ_EMIT_ARG
+#define GLZ_DOMINATED_AT_ONCE false
+#define LONE_CLASS(c) do { } while (0)
 #endif
 __shared__ GlzShared glz_sh;
 #ifdef GLZ_STAMPS
@@ -1264,7 +1305,9 @@ __device__ __forceinline__ int glz_resolve_general(GLZ_WIN_ARG const GlzDevJob &
     uint32_t sel = GLZ_SEL_RUN;
 
     *o_run = a & GLZ_A_RLE;
+    LONE_CLASS(4);
     if (a & GLZ_A_RLE) {
+        LONE_CLASS(0);
         /* glz_encode_tmpl.c:310-335: the run ends at the first pixel that
          * differs from its predecessor */
         const int j = glz_ffs_from(q0, q1, q2, q3, i + 3);
@@ -1309,6 +1352,7 @@ __device__ __forceinline__ int glz_resolve_general(GLZ_WIN_ARG const GlzDevJob &
                     table = true;
                 } else {
                     /* both were skipped: look for an older store to the slot */
+                    LONE_CLASS(1);
                     const uint32_t hi = glz_uniform(GLZ_W.hash[i]);
                     const uint64_t lo = (1ull << l) - 1;
                     int j = -1;
@@ -1346,6 +1390,7 @@ __device__ __forceinline__ int glz_resolve_general(GLZ_WIN_ARG const GlzDevJob &
             maxed = a & GLZ_A_GMAX;
             sel = GLZ_SEL_TABLE;
             if (maxed) {
+                LONE_CLASS(2);
                 const uint32_t rseg = glz_uniform(GLZ_W.g_seg[i]);
                 const GlzDevSeg rs = glz_seg(job, sh, rseg);
                 const GLZ_GLOBAL uint8_t *rbase = glz_seg_base(job, rseg, rs);
@@ -1353,11 +1398,30 @@ __device__ __forceinline__ int glz_resolve_general(GLZ_WIN_ARG const GlzDevJob &
                 int maxn = ip_bound - anchor;
                 const int rmax = (int)rs.nunits - ref;
                 maxn = rmax < maxn ? rmax : maxn;
+#ifdef GLZ_LONE
+                /* measured ahead of the walk?  The match of a head is the match of every position
+                 * behind it, up to its end, whose candidate lies at the same distance */
+                bool known = false;
+                const uint32_t hready = glz_uniform(*(volatile uint32_t *)&GLZ_W.heads_ready);
+                __builtin_amdgcn_wave_barrier(); /* the records are read after the flags */
+#pragma unroll
+                for (int hd = 0; hd < GLZ_HEADS; hd++) {
+                    const int hp = (int)glz_uniform((uint32_t)GLZ_W.head_pos[hd]);
+                    const int he = (int)glz_uniform((uint32_t)GLZ_W.head_end[hd]);
+                    if (!known && ((hready >> hd) & 1u) && hp >= 0 && hp <= i && glz_uniform(GLZ_W.head_seg[hd]) == rseg &&
+                        (int)glz_uniform((uint32_t)GLZ_W.head_delta[hd]) == ref - anchor && he - anchor >= len) {
+                        len = he - anchor;
+                        known = glz_uniform((uint32_t)GLZ_W.head_done[hd]) != 0;
+                    }
+                }
+                if (!known)
+#endif
                 len = glz_match_len<MODE>(base, anchor, rbase, ref, len, maxn, lane);
             }
         } else if (maxed) {
             /* a candidate inside the window: both sides are in the LDS tile as far
              * as it reaches, and most of these matches end a few pixels on */
+            LONE_CLASS(3);
             const int maxn = ip_bound - anchor;
             int checked = 0;
             len = glz_tile_match_len<MODE>(GLZ_W.tile, i, cand, maxn, lane, &checked);
@@ -1416,9 +1480,15 @@ __device__ __forceinline__ void glz_window_resolve(GLZ_WIN_ARG const GlzDevJob &
 #ifdef GLZ_STAMPS
             const long long f0 = STAMP();
 #endif
+#ifdef GLZ_LONE_STAMPS
+            const long long lf0 = LONE_STAMP();
+#endif
             glz_fast_stops(W, l, ins, stops, ms, last_len);
 #ifdef GLZ_STAMPS
             sh.st_fast += STAMP() - f0;
+#endif
+#ifdef GLZ_LONE_STAMPS
+            if (lane == 0) glz_sh.st_fast += LONE_STAMP() - lf0;
 #endif
             if (l >= 64) {
                 break;
@@ -1436,11 +1506,20 @@ __device__ __forceinline__ void glz_window_resolve(GLZ_WIN_ARG const GlzDevJob &
 #ifdef GLZ_STAMPS
                 const long long g0 = STAMP();
 #endif
+#ifdef GLZ_LONE_STAMPS
+                const long long lg0 = LONE_STAMP();
+#endif
                 const int len = glz_resolve_general<MODE>(GLZ_WIN_PASS job, base, ip, ip_bound, Q * 64 + l, sa, sb, ins, vfl,
                                                           q0, q1, q2, q3, lane, &run);
 #ifdef GLZ_STAMPS
                 sh.st_gen += STAMP() - g0;
                 sh.st_ngen++;
+#endif
+#ifdef GLZ_LONE_STAMPS
+                if (lane == 0) {
+                    glz_sh.st_gen[glz_sh.st_class] += LONE_STAMP() - lg0;
+                    glz_sh.st_ngen[glz_sh.st_class]++;
+                }
 #endif
                 slow |= bit;
                 stops |= bit;
@@ -1531,7 +1610,7 @@ __device__ __forceinline__ void glz_window_emit(GLZ_WIN_ARG const GlzDevJob &job
         if (my_hv && ((ins32[p >> 5] >> (p & 31)) & 1u)) {
             /* the last match's stores beyond the window are made after these, in
              * program order, so they win a shared slot by themselves */
-            bool dominated = false;
+            bool dominated = GLZ_DOMINATED_AT_ONCE;
             const uint32_t key = my_h & (GLZ_KEYS - 1);
             for (int v = p >> 5; v < 8 && !dominated; v++) {
                 uint32_t bits = GLZ_W.bitmap[GLZ_BM(key, (uint32_t)v)] & ins32[v];
