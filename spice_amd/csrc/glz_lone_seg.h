@@ -62,7 +62,7 @@ __device__ __forceinline__ void glz_load_tile(GlzWin &win, const GLZ_GLOBAL uint
  * in the same segment whose pixels are in prev's tile.  One position per lane. */
 template <int MODE>
 __device__ __forceinline__ void glz_window_fixup(GlzWin &win, const GlzWin &prev, uint32_t seg_idx, int ip,
-                                                 int ip_prev, int npix, int tid)
+                                                 int ip_prev, int npix, int tid, uint32_t newer_h0, uint32_t newer_h1)
 {
     typedef GlzTraits<MODE> T;
     const int p = tid, q = ip + p;
@@ -71,6 +71,9 @@ __device__ __forceinline__ void glz_window_fixup(GlzWin &win, const GlzWin &prev
         return; /* no table look-up here */
     }
     const uint32_t h = win.hash[p];
+    if (h == newer_h0 || h == newer_h1) {
+        return; /* the scan already gave this position a store that is newer than prev's */
+    }
     const uint32_t key = h & (GLZ_KEYS - 1);
     const uint32_t *ins32 = (const uint32_t *)prev.ins;
     int j = -1;
@@ -205,8 +208,10 @@ __device__ __forceinline__ void glz_parse_seg(const GlzDevJob &job, uint32_t seg
 
     if (tid == 0) {
         sh.arrive[0] = sh.arrive[1] = 0;
+        sh.stores_made = 0;
 #ifdef GLZ_LONE_STAMPS
         sh.st_fast = 0;
+        sh.st_x[0] = sh.st_x[1] = sh.st_x[2] = sh.st_x[3] = 0;
         for (int k = 0; k < 5; k++) {
             sh.st_gen[k] = sh.st_ngen[k] = 0;
         }
@@ -222,14 +227,18 @@ __device__ __forceinline__ void glz_parse_seg(const GlzDevJob &job, uint32_t seg
     int cur_ip = 0, ent_i = 0, ent_t0 = -1, ent_t1 = -1;
     int prv = -1, prv_ip = 0; /* slot and start of the window whose tokens are not out yet */
     bool heads_due = false;   /* win[cur]'s long matches have not been measured yet */
+    /* win[prv]'s table stores are made at the start of the step after its walk, beside the next
+     * walk, and the scanning wavefronts wait for them before they look at the table */
+    uint32_t stores_target = 0;                            /* what stores_made reaches when they are all made */
+    uint32_t prv_h0 = GLZ_NO_HASH, prv_h1 = GLZ_NO_HASH;   /* slots stored to right behind win[prv]'s ... */
+    int prv_next = 0;                                      /* ... for positions prv_next-2, prv_next-1 */
 #ifdef GLZ_LONE_STAMPS
-    long long a_p1 = 0, a_p2 = 0, a_role = 0, n_steps = 0, n_hits = 0, n_bubbles = 0, n_spec = 0;
+    long long a_p1 = 0, a_p2 = 0, a_role = 0, n_steps = 0, n_hits = 0, n_bubbles = 0, n_spec = 0, n_jumps = 0,
+              n_jump_hits = 0;
 #endif
 
     while (ready || prv >= 0 || ip < ip_limit) {
         const int nxt = cur == GLZ_SLOTS - 1 ? 0 : cur + 1;
-        const int nxt_ip = cur_ip + GLZ_WIN;
-        const bool spec = ready && nxt_ip < ip_limit;
 #ifdef GLZ_LONE_STAMPS
         const long long c0 = LONE_CLOCK();
 #endif
@@ -245,22 +254,51 @@ __device__ __forceinline__ void glz_parse_seg(const GlzDevJob &job, uint32_t seg
 #endif
             }
         } else if (role == GLZ_ROLE_SCAN) {
-            if (ready && heads_due) {
-                /* the window under the walk was scanned with the walk waiting for it */
-                glz_window_heads<MODE>(sh.win[cur], job, base, cur_ip, npix, gt, tgt);
+            int s_ip = ip;
+            bool scan = ip < ip_limit, jump = false;
+            if (ready) {
+                if (heads_due) {
+                    /* the window under the walk was scanned with the walk waiting for it */
+                    glz_window_heads<MODE>(sh.win[cur], job, base, cur_ip, npix, gt, tgt);
+                    glz_group_barrier(&sh.arrive[0], tgt, lane);
+                }
+                /* Where will the walk go from win[cur]?  If one of its measured matches leaves the
+                 * window, most likely through the first of them to where it ends; else into the
+                 * positions right behind the window. */
+                const GlzWin &cw = sh.win[cur];
+                s_ip = cur_ip + GLZ_WIN;
+                int first = GLZ_WIN;
+#pragma unroll
+                for (int hd = 0; hd < GLZ_HEADS; hd++) {
+                    const int hp = (int)glz_uniform((uint32_t)cw.head_pos[hd]);
+                    const int he = (int)glz_uniform((uint32_t)cw.head_end[hd]);
+                    if (hp >= 0 && hp < first && glz_uniform((uint32_t)cw.head_done[hd]) != 0 && he >= cur_ip + GLZ_WIN) {
+                        first = hp;
+                        s_ip = he;
+                        jump = true;
+                    }
+                }
+                scan = s_ip < ip_limit;
             }
-            if (ready ? spec : ip < ip_limit) {
-                GlzWin &w = sh.win[ready ? nxt : cur];
-                const int s_ip = ready ? nxt_ip : ip;
+            GlzWin &w = sh.win[ready ? nxt : cur];
+            if (gt == 0) {
+                w.start_ip = scan ? s_ip : -1;
+                w.jump = jump ? 1 : 0;
+            }
+            if (scan) {
                 glz_load_tile<MODE>(w, base, s_ip, npix, gt);
                 if (gt == 0) {
                     w.heads_ready = 0;
                 }
                 glz_group_barrier(&sh.arrive[0], tgt, lane);
-                /* a window scanned afresh: the table stores the last match left behind, now
-                 * that the pixels are here (position ip-2 first, then ip-1, as the reference
-                 * orders them).  A window scanned ahead of the walk has them inside it. */
-                const uint32_t pd = ready ? 0u : pend;
+                glz_wait_for(&sh.stores_made, stores_target); /* the table is up to date to win[prv]'s end */
+                /* The table stores the last match left behind for positions ip-2 and ip-1
+                 * (ip-2 first, as the reference orders them) are the newest entries of their
+                 * slots for this window.  Scanned afresh, the window knows of them and they
+                 * are made here, now that the pixels are in LDS; scanned where a long match
+                 * is expected to end, it counts on both and they are made once the walk has
+                 * got there; scanned right behind the window in front, it has them inside it. */
+                const uint32_t pd = ready ? (jump ? 3u : 0u) : pend;
                 uint32_t th0 = GLZ_NO_HASH, th1 = GLZ_NO_HASH;
                 if (pd) {
                     typedef GlzTraits<MODE> T;
@@ -268,7 +306,7 @@ __device__ __forceinline__ void glz_parse_seg(const GlzDevJob &job, uint32_t seg
                     const uint32_t c = w.tile[1] & T::MASK, d = w.tile[2] & T::MASK;
                     th0 = glz_hash3<MODE>(a, b, c);
                     th1 = glz_hash3<MODE>(b, c, d);
-                    if (gt == 0) {
+                    if (gt == 0 && !ready) {
                         if (pd & 1u) {
                             glz_htab_store(job, th0, seg_idx, (uint32_t)(s_ip - 2));
                         }
@@ -284,9 +322,17 @@ __device__ __forceinline__ void glz_parse_seg(const GlzDevJob &job, uint32_t seg
                     glz_window_heads<MODE>(w, job, base, s_ip, npix, gt, tgt);
                 }
             }
-        } else if (prv >= 0) {
+        } else if (role == GLZ_ROLE_EMIT && prv >= 0) {
             const uint32_t my_h = sh.win[prv].hash[gt];
-            glz_window_emit<MODE>(sh.win[prv], job, seg_idx, prv_ip, gt, my_h, prv_ip + gt + 2 < npix, tgt, false);
+            const bool my_hv = prv_ip + gt + 2 < npix;
+            glz_window_emit<MODE>(sh.win[prv], job, seg_idx, prv_ip, gt, my_h, my_hv, tgt, true, prv_h0, prv_h1);
+            if (prv_h0 != GLZ_NO_HASH && gt == 0) {
+                glz_htab_store(job, prv_h0, seg_idx, (uint32_t)(prv_next - 2));
+                glz_htab_store(job, prv_h1, seg_idx, (uint32_t)(prv_next - 1));
+            }
+            glz_signal(&sh.stores_made, lane);
+            glz_window_emit<MODE>(sh.win[prv], job, seg_idx, prv_ip, gt, my_h, my_hv, tgt, false, GLZ_NO_HASH,
+                                  GLZ_NO_HASH);
         }
 #ifdef GLZ_LONE_STAMPS
         const long long c1 = LONE_CLOCK();
@@ -301,13 +347,26 @@ __device__ __forceinline__ void glz_parse_seg(const GlzDevJob &job, uint32_t seg
             const int next_ip = (int)glz_uniform((uint32_t)cw.next_ip);
             const int r0 = (int)glz_uniform((uint32_t)cw.tail0), r1 = (int)glz_uniform((uint32_t)cw.tail1);
             const uint32_t cpend = glz_uniform(cw.pend);
-            const bool hit = spec && next_ip >= nxt_ip && next_ip < nxt_ip + GLZ_WIN && next_ip < ip_limit;
-            if (role == GLZ_ROLE_EMIT) {
-                const uint32_t my_h = cw.hash[gt];
-                glz_window_emit<MODE>(sh.win[cur], job, seg_idx, cur_ip, gt, my_h, cur_ip + gt + 2 < npix, tgt, true);
-            } else if (role == GLZ_ROLE_SCAN && spec) {
+            const int nxt_ip = (int)glz_uniform((uint32_t)sh.win[nxt].start_ip); /* -1: nothing was scanned */
+            const bool jump = glz_uniform((uint32_t)sh.win[nxt].jump) != 0;
+            const bool spec = nxt_ip >= 0;
+            const bool hit = spec && next_ip < ip_limit &&
+                             (jump ? next_ip == nxt_ip && cpend == 3u
+                                   : next_ip >= nxt_ip && next_ip < nxt_ip + GLZ_WIN);
+            /* a jump that came true: the stores behind the match (positions next_ip-2, next_ip-1)
+             * follow this window's stores; their pixels are in the scanned window's tile */
+            uint32_t th0 = GLZ_NO_HASH, th1 = GLZ_NO_HASH;
+            if (hit && jump) {
+                typedef GlzTraits<MODE> T;
+                const GlzWin &nw = sh.win[nxt];
+                const uint32_t a = nw.tile_m2 & T::MASK, b = nw.tile[0] & T::MASK;
+                const uint32_t c = nw.tile[1] & T::MASK, d = nw.tile[2] & T::MASK;
+                th0 = glz_hash3<MODE>(a, b, c);
+                th1 = glz_hash3<MODE>(b, c, d);
+            }
+            if (role == GLZ_ROLE_SCAN && spec) {
                 if (hit) {
-                    glz_window_fixup<MODE>(sh.win[nxt], cw, seg_idx, nxt_ip, cur_ip, npix, gt);
+                    glz_window_fixup<MODE>(sh.win[nxt], cw, seg_idx, nxt_ip, cur_ip, npix, gt, th0, th1);
                 } else if (nxt_ip + gt + 2 < npix) {
                     /* the guess was wrong: the slot's bitmap is clean again for its next window */
                     sh.win[nxt].bitmap[GLZ_BM(sh.win[nxt].hash[gt] & (GLZ_KEYS - 1), (uint32_t)gt >> 5)] = 0;
@@ -316,14 +375,18 @@ __device__ __forceinline__ void glz_parse_seg(const GlzDevJob &job, uint32_t seg
             __syncthreads();
             prv = cur;
             prv_ip = cur_ip;
+            prv_h0 = th0;
+            prv_h1 = th1;
+            prv_next = next_ip;
+            stores_target += 4;
             cur = nxt;
             ip = next_ip;
             heads_due = false;
             if (hit) {
                 cur_ip = nxt_ip;
                 ent_i = next_ip - nxt_ip;
-                ent_t0 = r0 >= GLZ_WIN ? r0 - GLZ_WIN : -1;
-                ent_t1 = r1 >= GLZ_WIN ? r1 - GLZ_WIN : -1;
+                ent_t0 = (!jump && r0 >= GLZ_WIN) ? r0 - GLZ_WIN : -1;
+                ent_t1 = (!jump && r1 >= GLZ_WIN) ? r1 - GLZ_WIN : -1;
                 pend = 0;
             } else {
                 ready = false;
@@ -332,6 +395,8 @@ __device__ __forceinline__ void glz_parse_seg(const GlzDevJob &job, uint32_t seg
 #ifdef GLZ_LONE_STAMPS
             n_hits += hit ? 1 : 0;
             n_spec += spec ? 1 : 0;
+            n_jumps += jump ? 1 : 0;
+            n_jump_hits += (jump && hit) ? 1 : 0;
 #endif
         } else {
             /* the scan (if any) has filled win[cur]; the tokens of prv are out */
@@ -366,6 +431,11 @@ __device__ __forceinline__ void glz_parse_seg(const GlzDevJob &job, uint32_t seg
             atomicAdd(&glz_lone_stamp_acc[6], (unsigned long long)n_hits);
             atomicAdd(&glz_lone_stamp_acc[7], (unsigned long long)n_bubbles);
             atomicAdd(&glz_lone_stamp_acc[8], (unsigned long long)n_spec);
+            atomicAdd(&glz_lone_stamp_acc[20], (unsigned long long)n_jumps);
+            atomicAdd(&glz_lone_stamp_acc[21], (unsigned long long)n_jump_hits);
+            for (int k = 0; k < 4; k++) {
+                atomicAdd(&glz_lone_stamp_acc[22 + k], (unsigned long long)sh.st_x[k]);
+            }
             atomicAdd(&glz_lone_stamp_acc[9], (unsigned long long)sh.st_fast);
             for (int k = 0; k < 5; k++) {
                 atomicAdd(&glz_lone_stamp_acc[10 + k], (unsigned long long)sh.st_gen[k]);

@@ -522,10 +522,44 @@ __device__ __forceinline__ void glz_group_barrier(uint32_t *ctr, uint32_t &targe
 
 #ifdef GLZ_LONE_STAMPS
 #define LONE_STAMP() clock64()
+#define LONE_ADD(k, v) do { if (lane == 0) glz_sh.st_x[k] += (v); } while (0)
 #define LONE_CLASS(c) do { if (lane == 0) glz_sh.st_class = (c); } while (0)
 #else
 #define LONE_CLASS(c) do { } while (0)
 #endif
+/* One group of wavefronts waits for what another has done: the doers add to a counter in LDS
+ * once their (global) stores are out, the waiters poll it. */
+#ifdef SPICE_WAVE_SIM
+__device__ __forceinline__ void glz_signal(uint32_t *ctr, int lane)
+{
+    if (lane == 0) {
+        *ctr += 1;
+        sim_note_progress();
+    }
+}
+__device__ __forceinline__ void glz_wait_for(uint32_t *ctr, uint32_t target)
+{
+    while (*(volatile uint32_t *)ctr < target) {
+        sim_yield();
+    }
+}
+#else
+__device__ __forceinline__ void glz_signal(uint32_t *ctr, int lane)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) {
+        atomicAdd(ctr, 1u);
+    }
+}
+__device__ __forceinline__ void glz_wait_for(uint32_t *ctr, uint32_t target)
+{
+    while (*(volatile uint32_t *)ctr < target) {
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+#endif
+
 /* The kernel for a GPU with few sessions keeps three windows in LDS: one being scanned,
  * one being walked, one being written out (glz_lone.hip). */
 #define GLZ_HEADS 4
@@ -569,8 +603,10 @@ struct GlzShared {
     uint32_t wave_sum[4];
     uint32_t op, copy, last_copy;      /* output cursor, see below */
     uint32_t arrive[2];                /* arrivals at the barriers of the scanning and the emitting wavefronts */
+    uint32_t stores_made;              /* wavefronts that have made their share of a window's table stores, ever */
 #ifdef GLZ_LONE_STAMPS
     long long st_fast, st_gen[5], st_ngen[5]; /* the walk: fast loop; general path by kind */
+    long long st_x[4];                        /* ... quarter set-up, quarter end, the rest of a window */
     int st_class;
 #endif
 };
@@ -1458,7 +1494,14 @@ __device__ __forceinline__ void glz_window_resolve(GLZ_WIN_ARG const GlzDevJob &
     int qnext = 0;        /* first quarter whose marks are not published yet */
     bool open = true;
 
+#ifdef GLZ_LONE_STAMPS
+    const long long w_in = LONE_STAMP();
+    long long w_acc = 0;
+#endif
     while (open && i < GLZ_WIN) {
+#ifdef GLZ_LONE_STAMPS
+        const long long qs0 = LONE_STAMP();
+#endif
         const int Q = i >> 6;
         /* quarters a match jumped over hold nothing but its tail's stores */
         for (int q = qnext; q < Q; q++) {
@@ -1474,6 +1517,11 @@ __device__ __forceinline__ void glz_window_resolve(GLZ_WIN_ARG const GlzDevJob &
         const uint32_t W = glz_quarter_words<MODE>(GLZ_WIN_PASS Q, lane, qa, qb);
         int l = i & 63;
         int last_len = 0;
+#ifdef GLZ_LONE_STAMPS
+        const long long qs1 = LONE_STAMP();
+        LONE_ADD(0, qs1 - qs0);
+        w_acc += qs1 - qs0;
+#endif
 
         while (l < 64) {
             /* ordinary stops: everything needed is in the quarter word */
@@ -1535,6 +1583,9 @@ __device__ __forceinline__ void glz_window_resolve(GLZ_WIN_ARG const GlzDevJob &
             }
         }
 
+#ifdef GLZ_LONE_STAMPS
+        const long long qe0 = LONE_STAMP();
+#endif
         i = Q * 64 + l;
         t0 = t1 = -1;
         if (open && last_len) {
@@ -1555,6 +1606,11 @@ __device__ __forceinline__ void glz_window_resolve(GLZ_WIN_ARG const GlzDevJob &
         }
         vfl |= (uint32_t)((ins >> lane) & 1) << Q;
         qnext = Q + 1;
+#ifdef GLZ_LONE_STAMPS
+        const long long qe1 = LONE_STAMP();
+        LONE_ADD(1, qe1 - qe0);
+        LONE_ADD(3, 1);
+#endif
     }
     /* quarters behind the last one walked: only tail stores can be in them */
     for (int q = qnext; q < 4; q++) {
@@ -1567,6 +1623,9 @@ __device__ __forceinline__ void glz_window_resolve(GLZ_WIN_ARG const GlzDevJob &
     /* Stores beyond the window (glz_encode_tmpl.c:424-444) wait for the next
      * window: its tile holds the pixels their hashes are made of, so they cost no
      * memory round trip here (glz_parse_seg makes them). */
+#ifdef GLZ_LONE_STAMPS
+    LONE_ADD(2, LONE_STAMP() - w_in);
+#endif
     if (lane == 0) {
         GLZ_W.next_ip = ip + i; /* i counts every pixel consumed, also past the window */
         GLZ_W.pend = (t0 >= GLZ_WIN ? 1u : 0u) | (t1 >= GLZ_WIN ? 2u : 0u);

@@ -142,6 +142,10 @@ uint64_t sim_exchange64(uint64_t v, int src_lane_or_neg, int mode, int arg);
 
 /* barrier of nthreads work-items of the workgroup that meet at `key` (wavefronts sharing a phase) */
 void sim_group_barrier(void *key, int nthreads);
+/* a work-item that polls memory another work-item will write lets the others run meanwhile;
+ * the writer says that something has moved on (the deadlock detector counts it) */
+void sim_yield(void);
+void sim_note_progress(void);
 
 static inline void __syncthreads() { sim_barrier(0); }
 static inline uint64_t __ballot(int pred) { return sim_exchange64(pred ? 1 : 0, -1, 0, 0); }

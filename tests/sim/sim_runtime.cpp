@@ -163,6 +163,17 @@ void sim_group_barrier(void *key, int nthreads)
     }
 }
 
+void sim_yield(void)
+{
+    wait_site[cur_fiber] = __builtin_return_address(0);
+    yield_to_sched();
+}
+
+void sim_note_progress(void)
+{
+    progress++;
+}
+
 uint64_t sim_exchange64(uint64_t v, int, int mode, int arg)
 {
     int tid = cur_fiber, wave = tid / 64, lane = tid % 64, width = wave_width(wave);

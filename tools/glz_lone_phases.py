@@ -38,7 +38,11 @@ for k in range(F):
           "stores + fix-up part %.0f | out %.0f KB"
           % (k, dt * 1e3, steps / S, a[8] / S, a[6] / S, 100.0 * a[6] / max(1, a[8]), a[7] / S,
              a[0] / steps, a[1] / steps, a[2] / steps, a[3] / steps, a[4] / steps, sizes.mean() / 1e3), flush=True)
-    walked = max(1, a[5] - a[7])          # steps with a walk = steps - waiting steps
+    print("         of the windows scanned ahead %.0f were placed where a long match was expected to end, %.0f rightly"
+          % (a[20] / S, a[21] / S), flush=True)
+    walked = max(1, a[5] - a[7])
+    print("         inside the walk, per walked window: %.1f quarters, quarter set-up %.0f, quarter end %.0f, whole walk function %.0f"
+          % (a[25] / walked, a[22] / walked, a[23] / walked, a[24] / walked), flush=True)          # steps with a walk = steps - waiting steps
     kinds = ["run leaving the window", "both nearest skipped", "table compare goes on", "window compare goes on", "other"]
     print("         per walked window (%.0f): walk %.0f cycles = fast loop %.0f + general path %s + rest"
           % (walked / S, a[0] / walked, a[9] / walked,
