@@ -344,6 +344,16 @@ int spice_gpu_glz_finish(SpiceGpuGlzJob *jobs, int njobs);
  * excluded: window bookkeeping, job staging, result hand-out. */
 uint64_t spice_gpu_glz_last_batch_host_ns(void);
 
+/* Two kernels parse GLZ images, with the same streams: one fits eight images on a CU
+ * (a full GPU: throughput is the number of sessions it holds), one gives an image a CU
+ * of its own and runs the scan of the next window, the walk over the current one's stops
+ * and the emit of the previous one side by side (an under-filled GPU: what counts is how
+ * soon one image is done).  A launch -- a batch, or one level of a batch whose jobs share
+ * dictionaries, or the callers a synchronous glz_encode round collected -- of at most
+ * njobs images uses the second.  Default: the device's number of CUs; 0: never; a
+ * negative number restores the default.  No counterpart in the reference. */
+void spice_gpu_glz_lone_max_jobs(int njobs);
+
 enum { SPICE_GPU_DCT_ISLOW = 0, SPICE_GPU_DCT_IFAST = 1 };
 
 /* One frame / still image for the JPEG kernels. */

@@ -166,7 +166,7 @@ EXPORTS = [
     "spice_gpu_mjpeg_rate_feed",
     "jpeg_encoder_create", "jpeg_encoder_destroy", "jpeg_encode",
     "spice_gpu_glz_out_bound", "spice_gpu_glz_encode_batch", "spice_gpu_glz_submit",
-    "spice_gpu_glz_finish", "spice_gpu_glz_last_batch_host_ns", "spice_gpu_jpeg_out_bound", "spice_gpu_jpeg_encode_batch",
+    "spice_gpu_glz_finish", "spice_gpu_glz_last_batch_host_ns", "spice_gpu_glz_lone_max_jobs", "spice_gpu_jpeg_out_bound", "spice_gpu_jpeg_encode_batch",
     "spice_gpu_jpeg_submit", "spice_gpu_jpeg_finish", "spice_gpu_jpeg_encode_noalloc", "spice_gpu_malloc", "spice_gpu_free",
     "spice_gpu_upload", "spice_gpu_download", "spice_gpu_get_stats", "spice_gpu_reset_stats",
     "spice_gpu_timing_enable", "spice_gpu_timing_reset", "spice_gpu_timing_read",
@@ -236,6 +236,7 @@ class SpiceGpu:
             getattr(L, n).restype = i
             getattr(L, n).argtypes = [C.POINTER(SpiceGpuGlzJob), i]
         L.spice_gpu_glz_last_batch_host_ns.restype = C.c_uint64
+        L.spice_gpu_glz_lone_max_jobs.argtypes = [i]
         L.spice_gpu_jpeg_out_bound.restype = C.c_size_t
         L.spice_gpu_jpeg_out_bound.argtypes = [i, i]
         for n in ("spice_gpu_jpeg_encode_batch", "spice_gpu_jpeg_submit", "spice_gpu_jpeg_finish"):

@@ -18,6 +18,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <memory>
@@ -748,12 +749,15 @@ struct LaunchStreams {
 };
 
 /* Launches of at most this many images use the kernel for an under-filled GPU: the number of
- * CUs of the device, or what SPICE_GPU_GLZ_LONE_MAX says (0: never; for measurements). */
+ * CUs of the device unless spice_gpu_glz_lone_max_jobs or SPICE_GPU_GLZ_LONE_MAX says otherwise
+ * (0: never). */
+std::atomic<int> g_lone_max{-1};
+
 int lone_max_jobs()
 {
-    static int cached = -1;
-    if (cached < 0) {
-        int v = 256;
+    int v = g_lone_max.load();
+    if (v < 0) {
+        v = 256;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, current_device() < 0 ? 0 : current_device()) == hipSuccess &&
             prop.multiProcessorCount > 0) {
@@ -763,9 +767,9 @@ int lone_max_jobs()
         if (e && *e) {
             v = atoi(e);
         }
-        cached = v;
+        g_lone_max.store(v);
     }
-    return cached;
+    return v;
 }
 
 /* Lays jobs, pools and copy descriptors out in the staging buffer, uploads
@@ -1625,6 +1629,11 @@ int spice_gpu_glz_finish(SpiceGpuGlzJob *jobs, int njobs)
         g_fl_cv.notify_all();
     }
     return rc;
+}
+
+void spice_gpu_glz_lone_max_jobs(int njobs)
+{
+    g_lone_max.store(njobs);
 }
 
 uint64_t spice_gpu_glz_last_batch_host_ns(void)

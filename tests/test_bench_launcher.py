@@ -29,7 +29,7 @@ def test_gpus_2_starts_two_ranks(sim):
     assert d["scaling"] == "weak" and d["unit"] == "Mpixels/s" and d["value"] > 0
     assert d["config"]["sessions_per_gpu"] == 3
     assert d["compression"]["images"] == 2 * 3 * 2           # ranks x sessions x timed steps
-    assert d["roofline"]["kernel"] == "glz_parse_kernel" and d["verified_sessions"] >= 2
+    assert d["roofline"]["kernel"] in ("glz_parse_kernel", "glz_parse_lone_kernel") and d["verified_sessions"] >= 2
 
 
 def test_a_launcher_that_disagrees_with_gpus_is_refused():

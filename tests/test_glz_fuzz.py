@@ -78,6 +78,7 @@ def test_sim_fuzz(sim, oracle, seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.usefixtures("both_glz_kernels")     # both GLZ parse kernels (tests/conftest.py)
 @pytest.mark.parametrize("seed", range(100, 124))
 def test_gpu_fuzz(gpu, oracle, seed):
     run_session(gpu, oracle, seed, 120, 700, 300)

@@ -16,6 +16,9 @@ from helpers import GlzPair, pixels_for, small_desktop, split_rows
 TYPES = [B.LZ_IMAGE_TYPE_RGB32, B.LZ_IMAGE_TYPE_RGBA, B.LZ_IMAGE_TYPE_RGB24, B.LZ_IMAGE_TYPE_RGB16]
 SIZES = [(64, 32), (100, 60), (7, 3), (1, 1), (3, 1), (200, 50), (2, 2), (130, 70), (6, 1), (7, 1)]
 
+# every test here runs through both GLZ parse kernels (tests/conftest.py)
+pytestmark = pytest.mark.usefixtures("both_glz_kernels")
+
 
 def run_mixed_sequence(dev, oracle, typ, nimages, window=40000, batch=False):
     """Small window so that images are evicted; ragged sizes; 1..3 chunks;

@@ -186,6 +186,7 @@ def test_sim_decode_of_device_streams(sim, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.usefixtures("both_glz_kernels")     # both GLZ parse kernels (tests/conftest.py)
 def test_gpu_multimon_4k(gpu, oracle):
     """four 3840x2160 monitors on one 16 Mi-pixel dictionary: a 3840x1512 region is 5.8 M
     pixels, so the window holds two and every image evicts its predecessor's predecessor"""
@@ -193,10 +194,12 @@ def test_gpu_multimon_4k(gpu, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.usefixtures("both_glz_kernels")     # both GLZ parse kernels (tests/conftest.py)
 def test_gpu_sessions64_glz_half(gpu, oracle):
     run_sessions64(gpu, oracle, 1920, 1080, nframes=3, window=16 * 1024 * 1024)
 
 
 @pytest.mark.gpu
+@pytest.mark.usefixtures("both_glz_kernels")     # both GLZ parse kernels (tests/conftest.py)
 def test_gpu_decode_of_device_streams(gpu, oracle):
     run_decode_of_device_streams(gpu, oracle)

@@ -16,7 +16,7 @@ gpu = B.SpiceGpu(lib); gpu.init(0)
 W, H = 1920, 1080
 dev = []
 for p in range(S):
-    seq = frames.DesktopSequence(W, H, seed=100 + p)
+    seq = frames.DesktopSequence(W, H, seed=int(os.environ.get("SEED0", "100")) + p)
     dev.append([gpu.to_device(seq.next()) for _ in range(F)])
 dicts = [B.GlzDictionary(gpu, 16 << 20, 1) for _ in range(S)]
 encs = [B.GlzEncoder(gpu, d, 0) for d in dicts]
