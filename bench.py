@@ -694,7 +694,8 @@ class MjpegWorkload:
         alg = self.F * self.W * self.H * 4 + out_bytes_timed / max(1, steps)
         main = self.dct and self.quality == 70
         r = roofline_of(self.kernel, alg, launches, ms,
-                        traffic=pmc_traffic("mjpeg2160", frames_per_step_per_gpu=self.F) if main else None)
+                        traffic=pmc_traffic("mjpeg2160", frames_per_step_per_gpu=self.F,
+                                            distinct_frames_per_gpu=self.pool) if main else None)
         # offsets + gather + finish, timed as one group
         tail = times.get("jpeg_bitstream_kernels", (0, 0.0))[1]
         r["bitstream_kernels_ms_per_launch"] = round(tail / launches, 3)

@@ -50,6 +50,13 @@ for w, name in names.items():
         for (d, k, c), v in sorted(acc.items()):
             f.write("%d,%s,%s,%d\n" % (d, k.replace("void ", ""), c, v))
 
+# the kernel for an under-filled GPU, when the round's script profiled it
+hits = glob.glob(os.path.join(src, "stats_sessions64/*/*_kernel_stats.csv"))
+if hits:
+    shutil.copy(hits[0], os.path.join(dst, "%s_sessions64_kernel_stats.csv" % tag))
+    line = [ln for ln in open(os.path.join(src, "sessions64_line.log")) if ln.startswith("{")][-1]
+    open(os.path.join(dst, "%s_sessions64_line.json" % tag), "w").write(line)
+
 with open(os.path.join(dst, "%s_pmc_hbm.csv" % tag), "w") as f:
     f.write("pass,dispatch_id,kernel,counter,KiB_summed_over_XCDs\n")
     for w, p in (("glz1080", "g"), ("mjpeg2160", "m")):

@@ -19,4 +19,7 @@ for w in glz1080 mjpeg2160; do
   timeout -s KILL 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $O/pmc_sq_$w -- python3 bench.py --workload $w --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --also 0 --verify 0 > $O/pmc_sq_$w.log 2>&1 || exit 1
   echo "pmc sq $w done"
 done
-find $O -name "*.csv" | head -40
+# the kernel for an under-filled GPU: sessions64 (32 images per step, a CU each)
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_sessions64 -- python3 bench.py --workload sessions64 --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end --also 0 --verify 0 > $O/sessions64_line.log 2>&1 || exit 1
+echo "stats sessions64 done"
+find $O -name "*.csv" | head -60
