@@ -76,14 +76,23 @@ __device__ __forceinline__ void glz_window_fixup(GlzWin &win, const GlzWin &prev
     }
     const uint32_t key = h & (GLZ_KEYS - 1);
     const uint32_t *ins32 = (const uint32_t *)prev.ins;
+    /* the row's eight words and the stores' eight words in one round trip: most positions find
+     * nothing, and eight dependent reads would be most of what this step costs */
+    uint32_t bm[8];
+#pragma unroll
+    for (int v = 0; v < 8; v++) {
+        bm[v] = prev.bitmap[GLZ_BM(key, (uint32_t)v)] & ins32[v];
+    }
     int j = -1;
-    for (int v = 7; v >= 0 && j < 0; v--) {
-        uint32_t bits = prev.bitmap[GLZ_BM(key, (uint32_t)v)] & ins32[v];
-        while (bits && j < 0) {
+#pragma unroll
+    for (int v = 7; v >= 0; v--) {
+        uint32_t bits = j < 0 ? bm[v] : 0u;
+        while (bits) {
             const int b = 31 - __clz((int)bits);
             bits &= ~(1u << b);
             if (prev.hash[v * 32 + b] == h) {
                 j = v * 32 + b;
+                bits = 0;
             }
         }
     }
