@@ -34,7 +34,7 @@ using namespace spicegpu;
 void glz_launch_parse(const GlzDevJob *jobs, int njobs, unsigned type_mask, const uint32_t *u32_pool,
                       const GlzDevSegUpdate *upd_pool, hipStream_t stream);
 void glz_launch_parse_lone(const GlzDevJob *jobs, int njobs, unsigned type_mask, const uint32_t *u32_pool,
-                           const GlzDevSegUpdate *upd_pool, hipStream_t stream);
+                           const GlzDevSegUpdate *upd_pool, hipStream_t stream, int skip_blocks);
 void glz_launch_copy(const GlzCopyDesc *descs, int ndescs, unsigned blocks_per_desc,
                      hipStream_t stream);
 
@@ -746,6 +746,7 @@ struct LaunchStreams {
     hipStream_t s;
     hipStream_t side;
     hipEvent_t fork, join;
+    int lone_skip = 0; /* glz_launch_parse_lone's skip_blocks: differs between launches that run side by side */
 };
 
 /* Launches of at most this many images use the kernel for an under-filled GPU: the number of
@@ -861,7 +862,7 @@ bool launch(Prepared *const *jobs, size_t n, Staging &st, size_t *results_off, b
     if ((int)n <= lone_max_jobs()) {
         glz_launch_parse_lone((const GlzDevJob *)(st.dev + off_jobs), (int)n, type_mask,
                               (const uint32_t *)(st.dev + off_u32),
-                              (const GlzDevSegUpdate *)(st.dev + off_upd), s);
+                              (const GlzDevSegUpdate *)(st.dev + off_upd), s, ls.lone_skip);
     } else {
         glz_launch_parse((const GlzDevJob *)(st.dev + off_jobs), (int)n, type_mask,
                          (const uint32_t *)(st.dev + off_u32),
@@ -898,29 +899,51 @@ bool launch(Prepared *const *jobs, size_t n, Staging &st, size_t *results_off, b
 /* Worker threads that call glz_encode at about the same time (one RedWorker
  * thread per display, server/red_dispatcher.c:1148) are served by one parse
  * launch: every caller has prepared its image and uploaded its rows, queues the
- * job, and the first one in becomes the round's leader, launches all queued
- * jobs together on its encoder's stream and hands each caller its result.
- * Callers that arrive while a round runs form the next round.  A device runs
- * the kernels of few streams side by side (it has a handful of hardware
- * queues), so separate launches from sixteen threads would mostly wait for one
- * another; one launch has a workgroup per caller.  Every caller holds its own
- * dictionary's lock meanwhile, so the jobs of a round are on distinct
- * dictionaries. */
+ * job, and the first one in becomes a round's leader, launches all queued jobs
+ * together and hands each caller its result.  A device runs the kernels of few
+ * streams side by side (it has a handful of hardware queues), so separate
+ * launches from sixteen threads would mostly wait for one another; one launch
+ * has a workgroup per caller.  Up to kRounds rounds run at a time, each on a
+ * stream of its own: a caller that arrives while a round runs does not wait for
+ * that round's images -- a thread with small images is not held up by its
+ * neighbours' large ones unless they arrive within the same half millisecond --
+ * and callers beyond that form the next round to start.  Every caller holds
+ * its own dictionary's lock meanwhile, so the jobs of all rounds are on
+ * distinct dictionaries. */
 struct Waiting {
     Prepared *job;
     int32_t size = 0;
     bool ok = false;
     bool done = false;
+    bool taken = false; /* a leader has this job in its round */
 };
 
+/* the device runs kSideBySide streams side by side: all but one carry rounds, the last the
+ * callers' row uploads and stream downloads, which must not queue behind a round's kernel */
+const int kRounds = kSideBySide - 1;
 struct Combiner {
     std::mutex m;
     std::condition_variable cv;
     std::vector<Waiting *> queue;
-    bool leader_active = false;
+    bool gathering = false; /* a leader is collecting its round: arrivals join it */
+    bool slot_busy[kRounds] = {false, false, false};
+    hipStream_t slot_stream[kSideBySide]; /* the rounds' streams: on different hardware queues */
+    bool streams_made = false, streams_ok = false;
     int entering = 0; /* callers that will queue a job shortly */
 };
 Combiner g_combiner;
+
+/* the stream a synchronous caller's copies go on (its encoder's own when the probe failed) */
+hipStream_t combiner_copy_stream(Encoder *enc)
+{
+    Combiner &c = g_combiner;
+    std::lock_guard<std::mutex> lk(c.m);
+    if (!c.streams_made) {
+        c.streams_made = true;
+        c.streams_ok = side_by_side_streams(c.slot_stream);
+    }
+    return c.streams_ok ? c.slot_stream[kSideBySide - 1] : enc->st;
+}
 
 void combiner_enter()
 {
@@ -947,29 +970,43 @@ bool combiner_run(Encoder *enc, Prepared *job, int32_t *size)
     c.queue.push_back(&me);
     c.cv.notify_all();
     while (!me.done) {
-        if (c.leader_active) {
+        int slot = -1;
+        if (!me.taken && !c.gathering) {
+            for (int k = 0; k < kRounds && slot < 0; k++) {
+                slot = c.slot_busy[k] ? -1 : k;
+            }
+        }
+        if (slot < 0) {
             c.cv.wait(lk);
             continue;
         }
-        /* lead this round: give the callers whose rows are already on their way to the
+        /* lead a round: give the callers whose rows are already on their way to the
          * device a moment (a caller counts itself in only after it has enqueued its upload,
          * so what is waited for is the rest of a copy, never another caller's allocations
          * or window bookkeeping) */
-        c.leader_active = true;
+        c.slot_busy[slot] = true;
+        c.gathering = true;
         const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(500);
         while (c.entering > 0 && c.cv.wait_until(lk, until) != std::cv_status::timeout) {
         }
         std::vector<Waiting *> round;
         round.swap(c.queue);
+        for (Waiting *w : round) {
+            w->taken = true;
+        }
+        c.gathering = false;
         lk.unlock();
         std::vector<Prepared *> ptrs;
         for (Waiting *w : round) {
             ptrs.push_back(w->job);
         }
         size_t res_off = 0;
-        bool ok = launch(ptrs.data(), ptrs.size(), enc->staging, &res_off, false,
-                         LaunchStreams{enc->st, nullptr, nullptr, nullptr});
-        ok = check(hipStreamSynchronize(enc->st), "glz sync") && ok;
+        /* this round's alone until slot_busy is cleared (the callers made the streams) */
+        const hipStream_t rs = c.streams_ok ? c.slot_stream[slot] : enc->st;
+        bool ok =
+                  launch(ptrs.data(), ptrs.size(), enc->staging, &res_off, false,
+                         LaunchStreams{rs, nullptr, nullptr, nullptr, 2 * slot});
+        ok = check(hipStreamSynchronize(rs), "glz sync") && ok;
         const int32_t *res = (const int32_t *)(enc->staging.host + res_off);
         lk.lock();
         for (size_t k = 0; k < round.size(); k++) {
@@ -977,7 +1014,7 @@ bool combiner_run(Encoder *enc, Prepared *job, int32_t *size)
             round[k]->size = ok ? res[k] : 0;
             round[k]->done = true;
         }
-        c.leader_active = false;
+        c.slot_busy[slot] = false;
         c.cv.notify_all();
     }
     *size = me.size;
@@ -1281,7 +1318,7 @@ int glz_encode(GlzEncoderContext *opaque_encoder, LzImageType type, int width, i
         *o_enc_dict_context = (GlzEncDictImageContext *)jobs[0].image;
     }
 
-    hipStream_t s = enc->st;
+    hipStream_t s = combiner_copy_stream(enc);
     bool ok = true;
     for (const GlzCopyDesc &c : jobs[0].copies) {
         ok = ok && check(hipMemcpyAsync(c.dst, c.src, c.bytes, hipMemcpyHostToDevice, s), "upload rows");

@@ -33,10 +33,13 @@ namespace glz_lone {
 template <int TYPE>
 __global__ void __launch_bounds__(GLZ_LONE_THREADS)
 glz_parse_lone_kernel(const GlzDevJob *__restrict__ jobs, const uint32_t *__restrict__ u32_pool,
-                      const GlzDevSegUpdate *__restrict__ upd_pool)
+                      const GlzDevSegUpdate *__restrict__ upd_pool, int skip_blocks)
 {
     GlzShared &sh = glz_sh;
-    const GlzDevJob job = jobs[blockIdx.x];
+    if ((int)blockIdx.x < skip_blocks) {
+        return; /* a place holder: see glz_launch_parse_lone */
+    }
+    const GlzDevJob job = jobs[(int)blockIdx.x - skip_blocks];
     if ((int)job.type != TYPE) {
         return; /* another instantiation of this kernel handles that pixel type */
     }
@@ -109,24 +112,29 @@ glz_parse_lone_kernel(const GlzDevJob *__restrict__ jobs, const uint32_t *__rest
 }
 } // namespace glz_lone
 
-/* type_mask: bit t set when some job has LzImageType t (6..9) */
+/* type_mask: bit t set when some job has LzImageType t (6..9).  skip_blocks: that many
+ * workgroups are launched in front of the jobs' and exit at once.  The hardware deals a
+ * launch's workgroups out over the GPU's eight XCDs in index order, so launches that run side by
+ * side on different streams with one or two images each would all start on the first XCD,
+ * on CUs that other launches' images are busy on; callers with several launches in flight give
+ * each a different offset. */
 void glz_launch_parse_lone(const GlzDevJob *jobs, int njobs, unsigned type_mask, const uint32_t *u32_pool,
-                           const GlzDevSegUpdate *upd_pool, hipStream_t stream)
+                           const GlzDevSegUpdate *upd_pool, hipStream_t stream, int skip_blocks)
 {
     using namespace glz_lone;
-    const dim3 grid((unsigned)njobs), block(GLZ_LONE_THREADS);
+    const dim3 grid((unsigned)(njobs + skip_blocks)), block(GLZ_LONE_THREADS);
     const int t = spicegpu::timing_begin("glz_parse_lone_kernel", stream);
     if (type_mask & (1u << 8)) {
-        hipLaunchKernelGGL(glz_parse_lone_kernel<8>, grid, block, 0, stream, jobs, u32_pool, upd_pool);
+        hipLaunchKernelGGL(glz_parse_lone_kernel<8>, grid, block, 0, stream, jobs, u32_pool, upd_pool, skip_blocks);
     }
     if (type_mask & (1u << 9)) {
-        hipLaunchKernelGGL(glz_parse_lone_kernel<9>, grid, block, 0, stream, jobs, u32_pool, upd_pool);
+        hipLaunchKernelGGL(glz_parse_lone_kernel<9>, grid, block, 0, stream, jobs, u32_pool, upd_pool, skip_blocks);
     }
     if (type_mask & (1u << 7)) {
-        hipLaunchKernelGGL(glz_parse_lone_kernel<7>, grid, block, 0, stream, jobs, u32_pool, upd_pool);
+        hipLaunchKernelGGL(glz_parse_lone_kernel<7>, grid, block, 0, stream, jobs, u32_pool, upd_pool, skip_blocks);
     }
     if (type_mask & (1u << 6)) {
-        hipLaunchKernelGGL(glz_parse_lone_kernel<6>, grid, block, 0, stream, jobs, u32_pool, upd_pool);
+        hipLaunchKernelGGL(glz_parse_lone_kernel<6>, grid, block, 0, stream, jobs, u32_pool, upd_pool, skip_blocks);
     }
     spicegpu::timing_end(t, stream);
 }

@@ -102,6 +102,83 @@ bool OwnStream::ensure()
     return st || check(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate");
 }
 
+namespace {
+/* occupies one wavefront for about `ticks` of the 100 MHz wall clock */
+__global__ void queue_probe_spin(long long ticks)
+{
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) {
+    }
+}
+
+/* does a kernel on b run while one on a is still running? */
+bool runs_beside(hipStream_t a, hipStream_t b)
+{
+    hipLaunchKernelGGL(queue_probe_spin, dim3(1), dim3(64), 0, a, 40000ll); /* 0.4 ms */
+    const uint64_t t0 = now_ns();
+    hipLaunchKernelGGL(queue_probe_spin, dim3(1), dim3(64), 0, b, 0ll);
+    bool ok = hipStreamSynchronize(b) == hipSuccess;
+    const uint64_t dt = now_ns() - t0;
+    ok = hipStreamSynchronize(a) == hipSuccess && ok;
+    if (getenv("SPICE_GPU_DEBUG_QUEUES")) {
+        fprintf(stderr, "queue probe: %p beside %p: %.3f ms\n", (void *)b, (void *)a, dt / 1e6);
+    }
+    return ok && dt < 200000; /* behind the long kernel it would have taken the 0.4 ms */
+}
+
+std::mutex g_sbs_mutex;
+hipStream_t g_sbs[kSideBySide];
+int g_sbs_state = 0; /* 0 not made, 1 made, -1 failed */
+} // namespace
+
+bool side_by_side_streams(hipStream_t out[kSideBySide])
+{
+    std::lock_guard<std::mutex> lk(g_sbs_mutex);
+    if (g_sbs_state == 0) {
+        g_sbs_state = -1;
+        const int kCandidates = 12;
+        std::vector<hipStream_t> kept, rejected;
+        hipEvent_t ev = nullptr;
+        bool ok = check(hipEventCreate(&ev), "hipEventCreate");
+        for (int c = 0; ok && c < kCandidates && (int)kept.size() < kSideBySide; c++) {
+            hipStream_t st = nullptr;
+            /* an event binds the stream to its queue now, not when a caller first uses it */
+            ok = check(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate") &&
+                 check(hipEventRecord(ev, st), "hipEventRecord") &&
+                 check(hipStreamSynchronize(st), "hipStreamSynchronize");
+            bool keep = ok;
+            for (size_t k = 0; keep && k < kept.size(); k++) {
+                keep = runs_beside(kept[k], st);
+            }
+            if (keep) {
+                kept.push_back(st);
+            } else if (st) {
+                rejected.push_back(st); /* stays until the end: destroyed now, its queue would be
+                                         * the least used one again and the next candidate's */
+            }
+        }
+        for (hipStream_t st : rejected) {
+            hipStreamDestroy(st);
+        }
+        if (ev) {
+            hipEventDestroy(ev);
+        }
+        if (ok && !kept.empty() && check(hipGetLastError(), "queue probe")) {
+            for (int k = 0; k < kSideBySide; k++) {
+                g_sbs[k] = kept[(size_t)k % kept.size()];
+            }
+            g_sbs_state = 1;
+        }
+    }
+    if (g_sbs_state != 1) {
+        return false;
+    }
+    for (int k = 0; k < kSideBySide; k++) {
+        out[k] = g_sbs[k];
+    }
+    return true;
+}
+
 bool DeviceGate::acquire(const char *who)
 {
     std::unique_lock<std::mutex> lk(g_gate_mutex);

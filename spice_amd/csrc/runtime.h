@@ -65,6 +65,16 @@ struct OwnStream {
     bool ensure();
 };
 
+/* kSideBySide streams whose kernels the device runs side by side.  A process has a handful of
+ * hardware queues, the runtime binds every stream to one of them when the stream is first
+ * given work (the least used one, by a rule of its own), and two streams on one queue run their
+ * kernels one after the other however independent they are.  So these are found by trying:
+ * candidates are created and bound, and one is kept when a short kernel on it finishes while
+ * a longer one still runs on each of those already kept (a few milliseconds, once per
+ * process).  Fewer distinct queues than asked for: the rest repeat the ones found. */
+const int kSideBySide = 4;
+bool side_by_side_streams(hipStream_t out[kSideBySide]);
+
 void stat_add(int codec, uint64_t orig, uint64_t comp, uint64_t ns);
 
 /* Brackets one kernel launch with events when timing is enabled (no-ops otherwise). */

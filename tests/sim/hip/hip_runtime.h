@@ -18,6 +18,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <functional>
 #include <type_traits>
@@ -148,6 +149,13 @@ void sim_yield(void);
 void sim_note_progress(void);
 
 static inline void __syncthreads() { sim_barrier(0); }
+/* the device's constant-rate clock (100 MHz) */
+static inline long long wall_clock64()
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (long long)ts.tv_sec * 100000000ll + ts.tv_nsec / 10;
+}
 static inline uint64_t __ballot(int pred) { return sim_exchange64(pred ? 1 : 0, -1, 0, 0); }
 static inline int __any(int pred) { return __ballot(pred) != 0; }
 static inline int __all(int pred);
