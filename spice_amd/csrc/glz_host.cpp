@@ -735,6 +735,15 @@ uint64_t g_last_host_ns = 0;
 
 bool flight_ready(Flight &f)
 {
+    /* the first two flights' four streams are ones the device runs side by side (a parse
+     * that queues behind the other flight's parse, or a copy behind a parse, loses what
+     * the second flight is for); further flights take what the runtime gives them */
+    const int idx = (int)(&f - g_flights);
+    hipStream_t pool[kSideBySide];
+    if (!f.main.st && idx < 2 && side_by_side_streams(pool)) {
+        f.main.st = pool[2 * idx];
+        f.side.st = pool[2 * idx + 1];
+    }
     return f.main.ensure() && f.side.ensure() &&
            (f.fork || check(hipEventCreate(&f.fork), "hipEventCreate")) &&
            (f.join || check(hipEventCreate(&f.join), "hipEventCreate"));
