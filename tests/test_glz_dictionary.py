@@ -184,14 +184,17 @@ def run_worker_threads(dev, oracle, nthreads=4, nimages=6):
     server/red_dispatcher.c:1148): every stream must be the one the oracle makes for that
     display alone."""
     import threading
-    w, h = 160, 64
-    per = [images(nimages, 200 + 10 * t, w, h)[0] for t in range(nthreads)]
-    gds = [B.GlzDictionary(dev, 30000, 1) for _ in range(nthreads)]
+    # displays of unequal size: the calls that arrive together share a launch, several such
+    # launches run at a time, and a small image must come out right beside a large one
+    sizes = [((160, 64), (320, 120), (96, 48), (200, 90))[t % 4] for t in range(nthreads)]
+    per = [images(nimages, 200 + 10 * t, *sizes[t])[0] for t in range(nthreads)]
+    gds = [B.GlzDictionary(dev, 120000, 1) for _ in range(nthreads)]
     ges = [B.GlzEncoder(dev, d, 0) for d in gds]
     got = [[] for _ in range(nthreads)]
     errs = []
 
     def work(t):
+        w, h = sizes[t]
         try:
             for px in per[t]:
                 got[t].append(ges[t].encode(T32, w, h, w * 4, [px])[0])
@@ -206,7 +209,8 @@ def run_worker_threads(dev, oracle, nthreads=4, nimages=6):
     try:
         assert not errs, errs
         for t in range(nthreads):
-            od = oracle.GlzDict(30000, 1)
+            w, h = sizes[t]
+            od = oracle.GlzDict(120000, 1)
             for k, px in enumerate(per[t]):
                 want, _ = od.encode(T32, w, h, w * 4, [px])
                 assert_same_stream(want, got[t][k], "thread %d image %d" % (t, k))
