@@ -36,7 +36,7 @@
 
 #include "glz_device.h"
 #include "runtime.h"
-#include "wave_ops.h"
+#include <spice_target.h>
 
 #include "glz_parse_phases.h"
 

@@ -18,7 +18,7 @@
 
 #include "glz_device.h"
 #include "runtime.h"
-#include "wave_ops.h"
+#include <spice_target.h>
 
 #define GLZ_LONE 1
 #ifdef GLZ_STAMPS

@@ -254,13 +254,9 @@ __device__ __forceinline__ void glz_parse_seg(const GlzDevJob &job, uint32_t seg
         /* ---- the three phases, side by side */
         if (role == GLZ_ROLE_WALK) {
             if (ready) {
-#ifndef SPICE_WAVE_SIM
-                __builtin_amdgcn_s_setprio(3);
-#endif
+                SPICE_SETPRIO(3);
                 glz_window_resolve<MODE>(sh.win[cur], job, seg_idx, base, cur_ip, npix, lane, ent_i, ent_t0, ent_t1);
-#ifndef SPICE_WAVE_SIM
-                __builtin_amdgcn_s_setprio(0);
-#endif
+                SPICE_SETPRIO(0);
             }
         } else if (role == GLZ_ROLE_SCAN) {
             int s_ip = ip;

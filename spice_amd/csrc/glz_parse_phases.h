@@ -52,18 +52,12 @@
 /* Pointers that arrive inside the job record are generic to the compiler; the
  * kernel retypes them as global memory so that loads through them are plain
  * global loads and values read at a wave-uniform address stay wave-uniform. */
-#ifdef SPICE_WAVE_SIM
-#define GLZ_GLOBAL
-#define GLZ_EIGHT_PER_CU
-#define GLZ_RECOMPUTE(v)
-#else
-#define GLZ_GLOBAL __attribute__((address_space(1)))
-#define GLZ_EIGHT_PER_CU __attribute__((amdgpu_waves_per_eu(8, 8))) /* 64 VGPRs */
+#define GLZ_GLOBAL SPICE_GLOBAL
+#define GLZ_EIGHT_PER_CU SPICE_WAVES_PER_EU(8) /* 64 VGPRs */
 /* Hides where a lane index came from: what is derived from it is worked out again in
  * every window (an instruction or two) instead of being hoisted out of the window loop
  * into registers that the 64-register budget then spills to scratch memory. */
-#define GLZ_RECOMPUTE(v) asm volatile("" : "+v"(v))
-#endif
+#define GLZ_RECOMPUTE(v) SPICE_OPAQUE_VGPR(v)
 typedef uint32_t glz_u32x4 __attribute__((vector_size(16)));
 typedef glz_u32x4 glz_u32x4_u __attribute__((aligned(4))); /* pixel-aligned only */
 
@@ -498,27 +492,10 @@ __device__ __forceinline__ uint32_t glz_hash_at(const GLZ_GLOBAL uint8_t *base, 
  * the group's counter in LDS and waits until the counter has reached what it was before plus
  * four.  The counter only grows; `target` is what the calling lane waits for next.  The
  * wavefronts of a group must all make the same barrier calls. */
-#ifdef SPICE_WAVE_SIM
 __device__ __forceinline__ void glz_group_barrier(uint32_t *ctr, uint32_t &target, int lane)
 {
-    (void)target;
-    (void)lane;
-    sim_group_barrier(ctr, 4 * GLZ_WAVE);
+    spice_group_barrier(ctr, target, lane, 4);
 }
-#else
-__device__ __forceinline__ void glz_group_barrier(uint32_t *ctr, uint32_t &target, int lane)
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lane == 0) {
-        atomicAdd(ctr, 1u);
-    }
-    target += 4;
-    while (*(volatile uint32_t *)ctr < target) {
-        __builtin_amdgcn_s_sleep(1);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-#endif
 
 #ifdef GLZ_LONE_STAMPS
 #define LONE_STAMP() clock64()
@@ -529,36 +506,14 @@ __device__ __forceinline__ void glz_group_barrier(uint32_t *ctr, uint32_t &targe
 #endif
 /* One group of wavefronts waits for what another has done: the doers add to a counter in LDS
  * once their (global) stores are out, the waiters poll it. */
-#ifdef SPICE_WAVE_SIM
 __device__ __forceinline__ void glz_signal(uint32_t *ctr, int lane)
 {
-    if (lane == 0) {
-        *ctr += 1;
-        sim_note_progress();
-    }
+    spice_signal(ctr, lane);
 }
 __device__ __forceinline__ void glz_wait_for(uint32_t *ctr, uint32_t target)
 {
-    while (*(volatile uint32_t *)ctr < target) {
-        sim_yield();
-    }
+    spice_wait_for(ctr, target);
 }
-#else
-__device__ __forceinline__ void glz_signal(uint32_t *ctr, int lane)
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lane == 0) {
-        atomicAdd(ctr, 1u);
-    }
-}
-__device__ __forceinline__ void glz_wait_for(uint32_t *ctr, uint32_t target)
-{
-    while (*(volatile uint32_t *)ctr < target) {
-        __builtin_amdgcn_s_sleep(1);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-#endif
 
 /* The kernel for a GPU with few sessions keeps three windows in LDS: one being scanned,
  * one being walked, one being written out (glz_lone.hip). */
@@ -989,14 +944,7 @@ __device__ __forceinline__ void glz_window_scan(GLZ_WIN_ARG const GlzDevJob &job
     int maxk;
     uint32_t gidist, gpdist;
     uint32_t r[GLZ_K];
-#ifdef SPICE_WAVE_SIM
-    capped = false;
-    maxk = 0;
-    gidist = gpdist = 0;
-    for (int k = 0; k < GLZ_K; k++) {
-        r[k] = 0;
-    }
-#endif
+    SPICE_LEFT_UNSET(capped = false; maxk = 0; gidist = gpdist = 0; for (int k = 0; k < GLZ_K; k++) { r[k] = 0; });
     {
         /* Straight-line up to the pixel requests: every test is a select on values all
          * lanes work out (a lane that does not look at the table works on the zero entry
@@ -1223,105 +1171,7 @@ __device__ __forceinline__ uint32_t glz_quarter_words(GLZ_WIN_ARG int Q, int lan
  * moves on.  Returns at the quarter's end (l >= 64) or at a stop that needs
  * glz_resolve_general.  A wavefront runs this at one instruction per ~5
  * cycles, so the loop is written out instruction by instruction. */
-__device__ __forceinline__ void glz_fast_stops(uint32_t W, int &l, uint64_t &ins, uint64_t &stops,
-                                               uint64_t &ms, int &last_len)
-{
-#ifdef SPICE_WAVE_SIM
-    while (l < 64) {
-        const uint32_t w = glz_readlane(W, l);
-        if (w & GLZ_W_SLOW) {
-            break;
-        }
-        const uint64_t bit = 1ull << l;
-        int len;
-        if (w & GLZ_W_RUN) {
-            len = (int)(w & 0x1ffu); /* a run stores nothing at its first position */
-        } else {
-            const int d1 = (int)(w & 63u), d2 = (int)((w >> GLZ_W_D2_SHIFT) & 63u);
-            len = ((ins >> d2) & 1) ? (int)((w >> GLZ_W_L2_SHIFT) & 31u) : (int)((w >> GLZ_W_LF_SHIFT) & 31u);
-            len = ((ins >> d1) & 1) ? (int)((w >> GLZ_W_L1_SHIFT) & 31u) : len;
-            if (len >= GLZ_W_LEN_MAXED) {
-                break;
-            }
-            ins |= bit;
-        }
-        stops |= bit;
-        if (len == 0) {
-            l++;
-        } else {
-            const uint64_t tm = len > 2 ? 3ull : 2ull;
-            const int sh0 = l + len - 2;
-            ms |= bit;
-            ins |= sh0 < 64 ? tm << sh0 : 0ull;
-            l += len;
-        }
-        last_len = len;
-    }
-#else
-    uint32_t w, len, t;
-    uint64_t bit, tm;
-    /* the operands below live in scalar registers; every lane holds the same values */
-    l = (int)glz_uniform((uint32_t)l);
-    last_len = (int)glz_uniform((uint32_t)last_len);
-    ins = glz_uniform64(ins);
-    stops = glz_uniform64(stops);
-    ms = glz_uniform64(ms);
-    asm volatile(
-        "s_cmp_lt_i32 %[l], 64\n"
-        "s_cbranch_scc0 9f\n"
-        "1:\n"
-        "s_nop 3\n"                                /* l was just written; it selects the lane */
-        "v_readlane_b32 %[w], %[W], %[l]\n"
-        "s_cmp_ge_u32 %[w], 0x40000000\n"
-        "s_cbranch_scc1 3f\n"                      /* GLZ_W_SLOW or GLZ_W_RUN */
-        "s_lshr_b32 %[t], %[w], 6\n"
-        "s_bitcmp1_b64 %[ins], %[t]\n"             /* bit index = low six bits: d2 */
-        "s_cselect_b32 %[t], 17, 22\n"
-        "s_bitcmp1_b64 %[ins], %[w]\n"             /* d1 */
-        "s_cselect_b32 %[t], 12, %[t]\n"
-        "s_lshr_b32 %[len], %[w], %[t]\n"
-        "s_and_b32 %[len], %[len], 31\n"
-        "s_cmp_gt_u32 %[len], 29\n"
-        "s_cbranch_scc1 9f\n"                      /* GLZ_W_LEN_MAXED, GLZ_W_LEN_DEEP */
-        "s_lshl_b64 %[bit], 1, %[l]\n"
-        "s_or_b64 %[stops], %[stops], %[bit]\n"
-        "s_or_b64 %[ins], %[ins], %[bit]\n"
-        "s_mov_b32 %[last], %[len]\n"
-        "s_cmp_eq_u32 %[len], 0\n"
-        "s_cbranch_scc1 2f\n"
-        "4:\n"
-        "s_or_b64 %[ms], %[ms], %[bit]\n"
-        "s_cmp_gt_u32 %[len], 2\n"
-        "s_cselect_b64 %[tm], 3, 2\n"
-        "s_add_i32 %[l], %[l], %[len]\n"
-        "s_add_i32 %[t], %[l], -2\n"
-        "s_lshl_b64 %[tm], %[tm], %[t]\n"
-        "s_cmp_lt_i32 %[t], 64\n"
-        "s_cselect_b64 %[tm], %[tm], 0\n"
-        "s_or_b64 %[ins], %[ins], %[tm]\n"
-        "s_cmp_lt_i32 %[l], 64\n"
-        "s_cbranch_scc1 1b\n"
-        "s_branch 9f\n"
-        "2:\n"
-        "s_add_i32 %[l], %[l], 1\n"
-        "s_cmp_lt_i32 %[l], 64\n"
-        "s_cbranch_scc1 1b\n"
-        "s_branch 9f\n"
-        "3:\n"                                     /* a run: no store at the stop itself */
-        "s_cmp_lt_i32 %[w], 0\n"
-        "s_cbranch_scc1 9f\n"
-        "s_and_b32 %[len], %[w], 0x1ff\n"
-        "s_lshl_b64 %[bit], 1, %[l]\n"
-        "s_or_b64 %[stops], %[stops], %[bit]\n"
-        "s_mov_b32 %[last], %[len]\n"
-        "s_branch 4b\n"
-        "9:\n"
-        : [l] "+s"(l), [ins] "+s"(ins), [stops] "+s"(stops), [ms] "+s"(ms), [last] "+s"(last_len),
-          [w] "=&s"(w), [len] "=&s"(len), [t] "=&s"(t), [bit] "=&s"(bit), [tm] "=&s"(tm)
-        : [W] "v"(W)
-        : "scc");
-#endif
-}
+#include <spice_target_glz_walk.h> /* glz_fast_stops: written for the target */
 
 /* The stops that need more than the quarter word: runs, compares that go on
  * past GLZ_K, slots whose two nearest predecessors were both skipped.  Returns
@@ -1936,13 +1786,9 @@ __device__ __forceinline__ void glz_parse_seg(const GlzDevJob &job, uint32_t seg
              * sessions, which have lanes to spare; it goes first (measured: a step of 3072
              * sessions 72.8 -> 71.2 ms; priorities for the other phases as well, 1 or 2
              * below this one, gave 71.6 - 72.1). */
-#ifndef SPICE_WAVE_SIM
-            __builtin_amdgcn_s_setprio(3);
-#endif
+            SPICE_SETPRIO(3);
             glz_window_resolve<MODE>(job, seg_idx, base, ip, npix, lane);
-#ifndef SPICE_WAVE_SIM
-            __builtin_amdgcn_s_setprio(0);
-#endif
+            SPICE_SETPRIO(0);
         }
         __syncthreads();
 #ifdef GLZ_STAMPS

@@ -10,15 +10,12 @@
  * byte per pixel of the bitmap: it is bound by HBM sector reads.
  */
 #include <hip/hip_runtime.h>
+#include <spice_target.h>
 
 #include "gradual_device.h"
 #include "runtime.h"
 
-#ifdef SPICE_WAVE_SIM
-#define GRAD_GLOBAL
-#else
-#define GRAD_GLOBAL __attribute__((address_space(1)))
-#endif
+#define GRAD_GLOBAL SPICE_GLOBAL
 
 struct GradPixel {
     int r, g, b;

@@ -24,13 +24,10 @@
  * strip bit counts, bit-granular concatenation, 0xFF byte stuffing.
  */
 #include <hip/hip_runtime.h>
-#ifndef SPICE_WAVE_SIM
-#include <hip/hip_ext.h>
-#endif
+#include <spice_target.h>
 
 #include "jpeg_device.h"
 #include "runtime.h"
-#include "wave_ops.h"
 
 #define JT JPEG_STRIP_THREADS
 #define JG_MCUS (JPEG_STRIP_MCUS * JPEG_GROUP_STRIPS)
@@ -40,15 +37,9 @@
 #define JCOEF_STRIDE 33                       /* words per block in LDS: 64 int16 + 1 against bank conflicts */
 #define JRING_WORDS 256                       /* per wavefront; a block adds at most 52 words */
 
-#ifdef SPICE_WAVE_SIM
-#define JPEG_GLOBAL
-#define JPEG_CONST
-#define JPEG_FOUR_PER_CU
-#else
-#define JPEG_GLOBAL __attribute__((address_space(1)))
-#define JPEG_CONST __attribute__((address_space(4))) /* read through the scalar cache */
-#define JPEG_FOUR_PER_CU __attribute__((amdgpu_waves_per_eu(4, 4)))
-#endif
+#define JPEG_GLOBAL SPICE_GLOBAL
+#define JPEG_CONST SPICE_CONST /* read through the scalar cache */
+#define JPEG_FOUR_PER_CU SPICE_WAVES_PER_EU(4)
 
 /* zigzag position -> natural index */
 #define JZZ_LIST \
@@ -308,11 +299,7 @@ __device__ __forceinline__ void jpeg_fdct(int (&c)[64])
 /* the n low bits of x (n < 32; none for n = 0): one bit-field extract */
 __device__ __forceinline__ uint32_t jpeg_low_bits(uint32_t x, int n)
 {
-#ifdef SPICE_WAVE_SIM
-    return x & ((1u << n) - 1);
-#else
-    return __builtin_amdgcn_ubfe(x, 0u, (uint32_t)n);
-#endif
+    return spice_low_bits(x, n);
 }
 
 /* packed table entry: size << 16 | code */
@@ -487,42 +474,25 @@ __device__ __forceinline__ void jpeg_ycc_pair(uint32_t p0, uint32_t p1, int &y0,
                                               int &cb1, int &cr0, int &cr1)
 {
     const float s = 1.0f / 65536.0f, k = (float)((128 << 16) + 32767) * s;
-#ifdef SPICE_WAVE_SIM
-    const uint32_t px[2] = {p0, p1};
-    int o[2][3];
-    for (int i = 0; i < 2; i++) {
-        const float b = (float)(px[i] & 0xff), g = (float)((px[i] >> 8) & 0xff), r = (float)((px[i] >> 16) & 0xff);
-        o[i][0] = (int)(b * (7471.0f * s) + (g * (38470.0f * s) + (r * (19595.0f * s) + 32768.0f * s)));
-        o[i][1] = (int)(g * (-21709.0f * s) + (r * (-11059.0f * s) + (b * 0.5f + k)));
-        o[i][2] = (int)(b * (-5329.0f * s) + (g * (-27439.0f * s) + (r * 0.5f + k)));
-    }
-    y0 = o[0][0];
-    cb0 = o[0][1];
-    cr0 = o[0][2];
-    y1 = o[1][0];
-    cb1 = o[1][1];
-    cr1 = o[1][2];
-#else
-    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef spice_f2 f2;
     const f2 b = {(float)(p0 & 0xff), (float)(p1 & 0xff)};
     const f2 g = {(float)((p0 >> 8) & 0xff), (float)((p1 >> 8) & 0xff)};
     const f2 r = {(float)((p0 >> 16) & 0xff), (float)((p1 >> 16) & 0xff)};
-    f2 y = __builtin_elementwise_fma(r, (f2)(19595.0f * s), (f2)(32768.0f * s));
-    y = __builtin_elementwise_fma(g, (f2)(38470.0f * s), y);
-    y = __builtin_elementwise_fma(b, (f2)(7471.0f * s), y);
-    f2 cb = __builtin_elementwise_fma(b, (f2)(0.5f), (f2)(k));
-    cb = __builtin_elementwise_fma(r, (f2)(-11059.0f * s), cb);
-    cb = __builtin_elementwise_fma(g, (f2)(-21709.0f * s), cb);
-    f2 cr = __builtin_elementwise_fma(r, (f2)(0.5f), (f2)(k));
-    cr = __builtin_elementwise_fma(g, (f2)(-27439.0f * s), cr);
-    cr = __builtin_elementwise_fma(b, (f2)(-5329.0f * s), cr);
+    f2 y = spice_fma2(r, (f2)(19595.0f * s), (f2)(32768.0f * s));
+    y = spice_fma2(g, (f2)(38470.0f * s), y);
+    y = spice_fma2(b, (f2)(7471.0f * s), y);
+    f2 cb = spice_fma2(b, (f2)(0.5f), (f2)(k));
+    cb = spice_fma2(r, (f2)(-11059.0f * s), cb);
+    cb = spice_fma2(g, (f2)(-21709.0f * s), cb);
+    f2 cr = spice_fma2(r, (f2)(0.5f), (f2)(k));
+    cr = spice_fma2(g, (f2)(-27439.0f * s), cr);
+    cr = spice_fma2(b, (f2)(-5329.0f * s), cr);
     y0 = (int)y.x;
     y1 = (int)y.y;
     cb0 = (int)cb.x;
     cb1 = (int)cb.y;
     cr0 = (int)cr.x;
     cr1 = (int)cr.y;
-#endif
 }
 
 /* Four stored pixels from the words of a row piece (4, 3 or 2 words by format) */
@@ -853,9 +823,7 @@ __device__ __forceinline__ void jpeg_strip_body(const JpegDevJob &job, const Jpe
         /* everything but the sign bit, in a vector register: the sign transfer
          * below is then one v_bfi_b32 */
         uint32_t magn = 0x7fffffffu;
-#ifndef SPICE_WAVE_SIM
-        asm volatile("" : "+v"(magn));
-#endif
+        SPICE_OPAQUE_VGPR(magn);
         /* The quotients go straight to the block's place in LDS, 16 bits each at
          * its zigzag position, as they are made: none of them stays in a
          * register waiting for its neighbour in zigzag order. */
@@ -1474,22 +1442,16 @@ void jpeg_launch(const JpegDevJob *jobs, int njobs, int max_groups, bool any_isl
      * other batch's, which waits for it. */
     hipEvent_t ta = nullptr, tb = nullptr;
     if (any_islow) {
-#ifndef SPICE_WAVE_SIM
         if (timed && spicegpu::timing_events("jpeg_strip_kernel_islow", &ta, &tb)) {
-            hipExtLaunchKernelGGL(jpeg_strip_kernel<false>, grid, dim3(JT), 0, ks, ta, tb, 0, jobs, huff);
-        } else
-#endif
-        {
+            SPICE_LAUNCH_TIMED(jpeg_strip_kernel<false>, grid, dim3(JT), ks, ta, tb, jobs, huff);
+        } else {
             hipLaunchKernelGGL(jpeg_strip_kernel<false>, grid, dim3(JT), 0, ks, jobs, huff);
         }
     }
     if (any_ifast) {
-#ifndef SPICE_WAVE_SIM
         if (timed && spicegpu::timing_events("jpeg_strip_kernel_ifast", &ta, &tb)) {
-            hipExtLaunchKernelGGL(jpeg_strip_kernel<true>, grid, dim3(JT), 0, ks, ta, tb, 0, jobs, huff);
-        } else
-#endif
-        {
+            SPICE_LAUNCH_TIMED(jpeg_strip_kernel<true>, grid, dim3(JT), ks, ta, tb, jobs, huff);
+        } else {
             hipLaunchKernelGGL(jpeg_strip_kernel<true>, grid, dim3(JT), 0, ks, jobs, huff);
         }
     }

@@ -23,8 +23,6 @@
 #include <functional>
 #include <type_traits>
 
-#define SPICE_WAVE_SIM 1
-
 #define __global__
 #define __device__
 #define __host__
