@@ -43,7 +43,7 @@ for k in range(F):
     walked = max(1, a[5] - a[7])
     print("         inside the walk, per walked window: %.1f quarters, quarter set-up %.0f, quarter end %.0f, whole walk function %.0f"
           % (a[25] / walked, a[22] / walked, a[23] / walked, a[24] / walked), flush=True)          # steps with a walk = steps - waiting steps
-    kinds = ["run leaving the window", "both nearest skipped", "table compare goes on", "window compare goes on", "other"]
+    kinds = ["run leaving the window", "both nearest skipped", "table compare goes on", "window compare goes on", "table compare measured ahead"]
     print("         per walked window (%.0f): walk %.0f cycles = fast loop %.0f + general path %s + rest"
           % (walked / S, a[0] / walked, a[9] / walked,
              ", ".join("%s %.2f x %.0f" % (kinds[k], a[15 + k] / walked, a[10 + k] / max(1, a[15 + k])) for k in range(5))),
