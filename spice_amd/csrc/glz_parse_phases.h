@@ -1300,6 +1300,9 @@ __device__ __forceinline__ int glz_resolve_general(GLZ_WIN_ARG const GlzDevJob &
                         known = glz_uniform((uint32_t)GLZ_W.head_done[hd]) != 0;
                     }
                 }
+                if (known) {
+                    LONE_CLASS(4); /* measured ahead of the walk */
+                }
                 if (!known)
 #endif
                 len = glz_match_len<MODE>(base, anchor, rbase, ref, len, maxn, lane);
