@@ -316,9 +316,10 @@ typedef struct SpiceGpuGlzJob {
 /* Bytes the output buffer of a job must hold in the worst case. */
 size_t spice_gpu_glz_out_bound(LzImageType type, int width, int height);
 
-/* Encodes njobs images in one call: a parse launch with a 256-lane workgroup
- * per job, and a copy of the rows into each dictionary's window in device
- * memory.  Jobs that share a dictionary (the display channels of one client,
+/* Encodes njobs images in one call: a parse launch with a workgroup per job
+ * (256 lanes, eight to a CU; 576 lanes and a CU each when the launch has no more
+ * jobs than the device has CUs, see spice_gpu_glz_lone_max_jobs), and a copy of the
+ * rows into each dictionary's window in device memory.  Jobs that share a dictionary (the display channels of one client,
  * server/red_worker.c:9677-9754) are encoded one after the other in the
  * caller's job order -- the batch is cut into as many launches as the most
  * images any one dictionary gets -- and produce exactly the streams that
@@ -335,9 +336,14 @@ size_t spice_gpu_glz_out_bound(LzImageType type, int width, int height);
  * fields say which job failed). */
 int spice_gpu_glz_encode_batch(SpiceGpuGlzJob *jobs, int njobs);
 
-/* As above but split in two so that callers can time the device work alone
- * with events on spice_gpu_stream(): submit enqueues everything, finish waits
- * and completes the host bookkeeping (post-encode window maintenance). */
+/* As above but split in two: submit enqueues everything and returns, finish waits
+ * and completes the host bookkeeping (post-encode window maintenance).  A thread may
+ * have up to FOUR batches in flight, over disjoint dictionaries (a batch that names a
+ * dictionary of one of the caller's batches in flight is refused): each runs on streams
+ * of its own, so while one batch's slowest images are still being parsed another
+ * batch's images take the places its quick ones have left.  finish completes the
+ * caller's OLDEST batch and takes that batch's job array; a fifth submit from the same
+ * thread is refused, another thread's submit waits for a free place. */
 int spice_gpu_glz_submit(SpiceGpuGlzJob *jobs, int njobs);
 int spice_gpu_glz_finish(SpiceGpuGlzJob *jobs, int njobs);
 /* Host time the last batch's submit + finish took, the wait for the device
