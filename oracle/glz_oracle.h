@@ -12,7 +12,7 @@
  * spice/macros.h from the un-vendored spice-common / spice-protocol trees) and
  * the reference holds no golden bitstreams for it.  What IS pinned:
  *   - the 33-byte header layout, against the header bytes of a reference run
- *     recorded during the survey of the reference (tests/golden/glz_header.json);
+ *     recorded when the reference was first studied (tests/golden/glz_header.json);
  *   - the wire format, by decoding every oracle stream with a restatement of
  *     the in-tree client decoder (client/glz_decode_tmpl.c:179-319,
  *     client/glz_decoder.cpp:51-105,238-301) and comparing pixels.
